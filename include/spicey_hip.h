@@ -1,0 +1,152 @@
+/*
+ * spicey_hip.h — C-ABI of the MI355X-native transient MNA solver that replaces the body of
+ * spicey's simulateTRAN().
+ *
+ * Boundary: the reference has no plugin/FFI layer; the boundary is cut INSIDE
+ *   simulateTRAN(ckt)            /root/reference/lib/analysis/simulateTRAN.ts:130-252
+ * The host (TypeScript via bun:ffi, or the Python mirror in spicey_amd/) keeps parsing,
+ * computeEffectiveTimeStep (:14-19), waveform pre-evaluation (:67, closures cannot cross FFI),
+ * flattening ParsedCircuit (parseNetlist.ts:85-105) into the POD arrays below, result re-keying
+ * and state write-back.  The native side runs the whole `for step … for iter …` nest
+ * (:146-238): stamping (:25-102, lib/stamping/stamp{Admittance,Current,VoltageSource}Real.ts), the linear solve that replaces
+ * solveReal (lib/math/solveReal.ts:3-73), the switch iteration (:108-128,:151-162), result
+ * recording (:164-219) and the state update (:221-237).
+ *
+ * Everything is plain C: POD structs, raw pointers and sizes, int32 status codes; no torch or
+ * C++ types.  A handle owns its device memory and is not thread-safe; distinct handles may be
+ * used from distinct threads.  The library never calls abort()/exit().
+ *
+ * Conventions
+ *   node ids      0 = ground, 1..n_nodes = non-ground nodes (NodeIndex.ts:28-31: row = id-1)
+ *   unknowns      x[0..n_nodes-1] node voltages, x[n_nodes+k] = branch current of source k
+ *                 (parseNetlist.ts:455-460)
+ *   instances     n_inst circuits sharing ONE topology (node ids, element order) with
+ *                 per-instance element values and state: every `double` array below is
+ *                 instance-major, [n_inst][n<kind>]
+ *   outputs       step-major: out_v[inst][step][n_out], out_i[inst][step][n_cur] with
+ *                 n_cur = nR+nC+nL+nV+nS+nD in the reference's recording order R,C,L,V,S,D
+ *                 (simulateTRAN.ts:173-219)
+ */
+#ifndef SPICEY_HIP_H
+#define SPICEY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPICEY_ABI_VERSION 1
+
+/* status codes (SURVEY.md §8(b) "Errors") */
+#define SPICEY_OK 0
+#define SPICEY_ERR_SINGULAR 1 /* host maps to Error("Singular matrix (real)"), solveReal.ts:28 */
+#define SPICEY_ERR_BAD_DESC 2
+#define SPICEY_ERR_HIP 3
+#define SPICEY_ERR_NO_DEVICE 4 /* the product path has no CPU fallback: no GPU -> this error */
+
+/* Flat circuit descriptor: the ParsedCircuit of parseNetlist.ts:85-105 as SoA arrays.
+ * All pointers are HOST pointers, read during spicey_create only. */
+typedef struct SpiceyDesc {
+  int32_t abi_version; /* SPICEY_ABI_VERSION */
+  int32_t n_nodes;     /* ckt.nodes.count() - 1 */
+  int32_t n_inst;      /* >= 1 */
+  int32_t nR, nC, nL, nV, nS, nD;
+
+  /* resistors  (ParsedResistor, parseNetlist.ts:12) */
+  const int32_t *R_n1, *R_n2; /* [nR] */
+  const double *R_val;        /* [n_inst][nR] ohms */
+  /* capacitors (ParsedCapacitor :13-19); C_vprev = state entering the run (vPrev) */
+  const int32_t *C_n1, *C_n2;
+  const double *C_val, *C_vprev; /* [n_inst][nC] */
+  /* inductors (ParsedInductor :20-26); L_iprev = iPrev */
+  const int32_t *L_n1, *L_n2;
+  const double *L_val, *L_iprev; /* [n_inst][nL] */
+  /* independent voltage sources (ParsedVoltageSource :34-43); values come per step in src_table */
+  const int32_t *V_n1, *V_n2; /* [nV] */
+  /* voltage-controlled switches (ParsedSwitch :63-72 + ParsedVSwitchModel :45-51) */
+  const int32_t *S_n1, *S_n2, *S_cp, *S_cn;          /* [nS] */
+  const double *S_ron, *S_roff, *S_von, *S_voff;     /* [n_inst][nS] */
+  const int32_t *S_ison;                             /* [n_inst][nS] 0/1, state entering the run */
+  /* diodes (ParsedDiode :53-61 + ParsedDiodeModel :28-32); D_vdprev = vdPrev */
+  const int32_t *D_np, *D_nm;                        /* [nD] */
+  const double *D_is, *D_n, *D_vdprev;               /* [n_inst][nD] */
+
+  /* recorded node voltages: out_nodes[n_out] are node ids (1-based); n_out = 0 / NULL -> all
+   * nodes in id order (simulateTRAN.ts:164-171; .PRINT filtering :240-249 done before writing) */
+  int32_t n_out;
+  const int32_t *out_nodes;
+} SpiceyDesc;
+
+typedef struct SpiceyOptions {
+  int32_t device;        /* HIP device ordinal */
+  int32_t threads;       /* workgroup size, 0 = auto */
+  int32_t inst_per_wg;   /* instances interleaved in one workgroup's LDS, 0 = auto */
+  int32_t want_currents; /* 1: record element currents (out_i) */
+  int32_t force_global;  /* 1: keep the LU workspace in HBM/L2 even if it fits LDS (testing) */
+  int32_t reserved[3];
+} SpiceyOptions;
+
+typedef struct SpiceyInfo {
+  int32_t n_var;       /* n_nodes + nV */
+  int32_t nnz_a;       /* structural nonzeros of A */
+  int32_t nnz_lu;      /* nonzeros of L+U (incl. fill) under the chosen ordering */
+  int32_t n_levels;    /* elimination-tree height = barrier-separated factor phases */
+  int32_t threads;
+  int32_t inst_per_wg;
+  int32_t lds_bytes;   /* dynamic LDS per workgroup; 0 = global workspace */
+  int32_t n_cur;       /* element-current columns */
+  int32_t n_out;       /* recorded node-voltage columns */
+  int32_t n_workgroups;
+  int64_t program_bytes;            /* device-side schedule ("program") size */
+  int64_t algorithmic_bytes_solve;  /* SURVEY.md §8(d) formula */
+} SpiceyInfo;
+
+typedef struct SpiceyHandle SpiceyHandle;
+
+/* Symbolic phase (MNA pattern, zero-free-diagonal row matching, nested-dissection ordering,
+ * symbolic LU, level schedule) + upload.  Replaces the per-iteration dense allocation and
+ * pivot search of simulateTRAN.ts:152-153 / solveReal.ts:15-34. */
+int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *opt, SpiceyHandle **out);
+
+/* One transient run of `steps`+1 points (step = 0..steps inclusive, t = step*dt;
+ * simulateTRAN.ts:146-147) for all instances, continuing from the handle's current state
+ * (a second run continues like the reference does).
+ *   src_table   [steps+1][nV] source values at t = step*dt, shared by all instances
+ *   out_v       [n_inst][steps+1][n_out]
+ *   out_i       [n_inst][steps+1][n_cur] or NULL
+ *   iters       [n_inst][steps+1] iterations executed per step (1..20) or NULL
+ * HOST buffers; blocking. */
+int32_t spicey_run(SpiceyHandle *h, int64_t steps, double dt, const double *src_table,
+                   double *out_v, double *out_i, int32_t *iters);
+
+/* Same with DEVICE buffers, enqueued on `stream` (a hipStream_t, NULL = default stream) without
+ * synchronising: the error word is checked by spicey_sync(). */
+int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, const double *d_src_table,
+                          double *d_out_v, double *d_out_i, int32_t *d_iters, void *stream);
+/* Wait for enqueued runs; returns SPICEY_ERR_SINGULAR etc. like spicey_run. */
+int32_t spicey_sync(SpiceyHandle *h);
+
+/* Final state after the last run (write-back to ckt: simulateTRAN.ts:221-237,122-124).
+ * Any pointer may be NULL.  Arrays are [n_inst][n<kind>]. */
+int32_t spicey_get_state(SpiceyHandle *h, double *C_vprev, double *L_iprev, double *D_vdprev,
+                         int32_t *S_ison);
+
+/* Total solves (= sum of iterations) executed by the last run, all instances. */
+int64_t spicey_last_solve_count(SpiceyHandle *h);
+/* Duration in ms of the last run's kernel, measured with HIP events on the launch stream. */
+double spicey_last_kernel_ms(SpiceyHandle *h);
+
+int32_t spicey_get_info(SpiceyHandle *h, SpiceyInfo *info);
+/* Human-readable description of the last error ("singular at inst 0 step 3 iter 0", the
+ * hipGetErrorString text, …).  Valid until the next call on the handle. NULL handle -> global. */
+const char *spicey_last_error(SpiceyHandle *h);
+void spicey_destroy(SpiceyHandle *h);
+
+/* Library build info: "spicey_hip <abi> gfx950 …" */
+const char *spicey_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPICEY_HIP_H */

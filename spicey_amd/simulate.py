@@ -1,0 +1,135 @@
+"""simulate() / simulateTRAN(): the reference's public API with the native solver underneath.
+
+Mirrors /root/reference/lib/analysis/simulate.ts:5-10 and simulateTRAN.ts:130-252: same result
+shapes ({times, nodeVoltages, elementCurrents} keyed by canonical node / element name, JS key
+order), same in-place mutation of the circuit's state fields, same Error messages.
+
+The work between "flatten" and "re-key" is ONE blocking call into libspicey_hip.so
+(spicey_amd/lib.py).  There is no CPU path here: without the HIP library or a GPU this raises.
+A backend object can be injected for tests (tests/ use the oracle through it to check the
+flatten / re-key logic on CPU); the default is always the HIP backend.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import abi
+from .netlist import ParsedCircuit, js_object_key_order, parseNetlist
+
+
+class SingularMatrixError(RuntimeError):
+    """The reference throws Error("Singular matrix (real)") (solveReal.ts:28)."""
+
+    def __init__(self, detail: str = "") -> None:
+        super().__init__("Singular matrix (real)")
+        self.detail = detail
+
+
+def _default_backend():
+    from .lib import HipBackend  # fails loudly if the extension is missing
+
+    return HipBackend()
+
+
+def simulateTRAN(ckt: ParsedCircuit, backend=None, as_lists: bool = True) -> Optional[dict]:
+    tran = ckt.analyses.get("tran")
+    if not tran:
+        return None
+    dt, steps = abi.computeEffectiveTimeStep(tran["dt"], tran["tstop"])
+    flat = abi.flatten(ckt)
+    src = abi.source_table(ckt, dt, steps)
+    be = backend if backend is not None else _default_backend()
+    res = be.run(flat, steps, dt, src, want_currents=True)
+    if res["status"] == abi.ERR_SINGULAR:
+        raise SingularMatrixError(res.get("detail", ""))
+    if res["status"] != abi.OK:
+        raise RuntimeError(res.get("detail", f"spicey native error {res['status']}"))
+
+    out_v = res["out_v"][0]  # [steps+1][n_nodes]
+    out_i = res["out_i"][0]  # [steps+1][n_cur]
+    conv = (lambda a: a.tolist()) if as_lists else (lambda a: a)
+
+    times = [step * dt for step in range(steps + 1)]  # t = step*dt (:147), first push is 0
+    times[0] = 0.0
+
+    names = ckt.nodes.rev
+    node_voltages: Dict[str, object] = {}
+    # JS: later duplicate names cannot occur (interned), order = js key order of insertion order
+    order = js_object_key_order([names[i] for i in range(1, ckt.nodes.count())])
+    col = {names[i]: i - 1 for i in range(1, ckt.nodes.count())}
+    for name in order:
+        node_voltages[name] = conv(out_v[:, col[name]])
+
+    # element currents: R, C, L, V, S, D recording order (:173-219); duplicate names append to the
+    # same JS array, interleaved per step
+    elem_names: List[str] = ([e.name for e in ckt.R] + [e.name for e in ckt.C] + [e.name for e in ckt.L]
+                             + [e.name for e in ckt.V] + [e.name for e in ckt.S if e.model is not None]
+                             + [e.name for e in ckt.D if e.model is not None])
+    element_currents: Dict[str, object] = {}
+    groups: Dict[str, List[int]] = {}
+    for j, nm in enumerate(elem_names):
+        groups.setdefault(nm, []).append(j)
+    for nm in js_object_key_order(elem_names):
+        cols = groups[nm]
+        if len(cols) == 1:
+            element_currents[nm] = conv(out_i[:, cols[0]])
+        else:
+            element_currents[nm] = conv(out_i[:, cols].reshape(-1))
+
+    # state write-back (:221-237, :122-124)
+    st = res["state"]
+    for i, c in enumerate(ckt.C):
+        c.vPrev = float(st["C_vprev"][0, i])
+    for i, l in enumerate(ckt.L):
+        l.iPrev = float(st["L_iprev"][0, i])
+    for i, d in enumerate([d for d in ckt.D if d.model is not None]):
+        d.vdPrev = float(st["D_vdprev"][0, i])
+    for i, s in enumerate([s for s in ckt.S if s.model is not None]):
+        s.isOn = bool(st["S_ison"][0, i])
+
+    if len(ckt.probes["tran"]) > 0:  # :240-249
+        upper = [p.upper() for p in ckt.probes["tran"]]
+        node_voltages = {k: v for k, v in node_voltages.items() if k.upper() in upper}
+    return {"times": times, "nodeVoltages": node_voltages, "elementCurrents": element_currents,
+            "iterations": res.get("iters")}
+
+
+def simulate(netlist_text: str, backend=None) -> dict:
+    """simulate.ts:5-10.  `ac` is out of scope for this build and always None."""
+    circuit = parseNetlist(netlist_text)
+    tran = simulateTRAN(circuit, backend=backend)
+    return {"circuit": circuit, "ac": None, "tran": tran}
+
+
+def formatTranResult(tran: Optional[dict]) -> str:
+    """/root/reference/lib/formatting/formatTranResult.ts:1-23 (toPrecision(6) CSV)."""
+    if not tran:
+        return "No TRAN analysis.\n"
+    nodes = list(tran["nodeVoltages"].keys())
+    lines = [", ".join(["t(s)"] + [f"{n}:V" for n in nodes])]
+    for k, t in enumerate(tran["times"]):
+        row = [_to_precision6(t)]
+        for n in nodes:
+            series = tran["nodeVoltages"][n]
+            if k < len(series):
+                row.append(_to_precision6(float(series[k])))
+        lines.append(", ".join(row))
+    return "\n".join(lines)
+
+
+def _to_precision6(x: float) -> str:
+    """Number.prototype.toPrecision(6)."""
+    if x != x:
+        return "NaN"
+    if x in (float("inf"), float("-inf")):
+        return "Infinity" if x > 0 else "-Infinity"
+    if x == 0:
+        return "0.00000"
+    s = f"{x:.5e}"
+    mant, exp = s.split("e")
+    e = int(exp)
+    if e < -6 or e >= 6:
+        return f"{mant}e{'+' if e >= 0 else '-'}{abs(e)}"
+    return f"{x:.{max(0, 5 - e)}f}"

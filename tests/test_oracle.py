@@ -1,0 +1,135 @@
+"""Pin the oracle (oracle/spicey_ref.c + the Python parser/flatten mirror) bit-for-bit against
+outputs of the reference's own TRAN path (tests/golden/*.json, made by
+tools/js_oracle/make_golden.py) and against the reference's decoded SVG snapshots."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import (GOLD, LARGE_GOLDENS, SMALL_GOLDENS, bits_equal, farr, fnum, golden_netlist, load_golden)
+from spicey_amd import abi
+from spicey_amd.netlist import parseNetlist
+from spicey_amd.simulate import SingularMatrixError, formatTranResult, simulateTRAN
+
+
+@pytest.mark.parametrize("name", SMALL_GOLDENS)
+def test_small_goldens_bit_exact(name, oracle_backend):
+    g = load_golden(name)
+    ckt = parseNetlist(golden_netlist(g))
+    assert ckt.nodes.rev == g["nodes"]
+    assert ckt.probes["tran"] == g["probes"]
+    assert ckt.skipped == g["skipped"]
+    assert {k: len(getattr(ckt, k)) for k in "RCLVSD"} == g["counts"]
+    for kind in "RCL":
+        assert [[e.name, e.n1, e.n2, getattr(e, kind)] for e in getattr(ckt, kind)] == g["elements"][kind]
+    assert [[s.name, s.n1, s.n2, s.ncPos, s.ncNeg, s.model.Ron, s.model.Roff, s.model.Von, s.model.Voff] for s in ckt.S] == g["elements"]["S"]
+    assert [[d.name, d.nPlus, d.nMinus, d.model.Is, d.model.N] for d in ckt.D] == g["elements"]["D"]
+    for ri, run in enumerate(g["runs"]):  # run 2 continues from run 1's end state
+        res = simulateTRAN(ckt, backend=oracle_backend)
+        assert list(res["nodeVoltages"]) == run["keysV"]
+        assert list(res["elementCurrents"]) == run["keysI"]
+        assert res["times"] == run["times"]
+        for k in run["keysV"]:
+            assert bits_equal(res["nodeVoltages"][k], farr(run["V"][k])).all(), (name, ri, k)
+        for k in run["keysI"]:
+            assert bits_equal(res["elementCurrents"][k], farr(run["I"][k])).all(), (name, ri, k)
+        assert [c.vPrev for c in ckt.C] == run["state"]["C_vPrev"]
+        assert [l.iPrev for l in ckt.L] == run["state"]["L_iPrev"]
+        assert [d.vdPrev for d in ckt.D] == run["state"]["D_vdPrev"]
+        assert [int(s.isOn) for s in ckt.S] == run["state"]["S_isOn"]
+        if ri == 0 and "formatted_head" in run:
+            assert formatTranResult(res).split("\n")[:4] == run["formatted_head"]
+
+
+@pytest.mark.parametrize("name", LARGE_GOLDENS)
+def test_large_goldens_sha256(name, oracle_backend):
+    """1000-unknown prefixes of BASELINE configs 2/3 (SURVEY.md Appendix C spot values + sha256)."""
+    g = load_golden(name)
+    ckt = parseNetlist(golden_netlist(g))
+    res = simulateTRAN(ckt, backend=oracle_backend, as_lists=False)
+    assert list(res["nodeVoltages"]) == g["keysV"] and list(res["elementCurrents"]) == g["keysI"]
+    V = np.stack([res["nodeVoltages"][k] for k in g["keysV"]], axis=1)
+    I = np.stack([res["elementCurrents"][k] for k in g["keysI"]], axis=1)
+    assert V.shape[0] == g["npoints"]
+    assert hashlib.sha256(np.ascontiguousarray(V).tobytes()).hexdigest() == g["sha256_V"]
+    assert hashlib.sha256(np.ascontiguousarray(I).tobytes()).hexdigest() == g["sha256_I"]
+    for k, series in g["V_nodes"].items():
+        assert bits_equal(res["nodeVoltages"][k], farr(series)).all()
+
+
+def test_appendix_c_spot_values(oracle_backend):
+    g = load_golden("rc1000_200")
+    assert g["sha256_V"] == "54438181f9e09096127a9163c41f81e142c606eb6e6c55f5176fb1e27b1b1ea8"
+    assert g["V_nodes"]["n2"][1] == 4.510237884227233 and g["V_nodes"]["n1000"][200] == 2.303629467015315e-06
+    g = load_golden("dchain1000_200")
+    assert g["sha256_V"] == "908061ae7a0cb84f93b64747a763f629b659e28d14fe78b74e8b152c5cfb76cd"
+    assert g["V_nodes"]["n2"][1] == 3.613634986544149 and g["V_nodes"]["n2"][200] == 0.7504015734687133
+
+
+@pytest.mark.parametrize("name", ["err_singular", "err_vloop"])
+def test_singular_errors(name, oracle_backend):
+    g = load_golden(name)
+    assert g["error"] == "Singular matrix (real)"
+    ckt = parseNetlist(golden_netlist(g))
+    with pytest.raises(SingularMatrixError, match=r"Singular matrix \(real\)"):
+        simulateTRAN(ckt, backend=oracle_backend)
+
+
+def test_readme_rc_config1(oracle_backend):
+    """BASELINE config 1: README netlist + .tran 1us 10ms -> 10000 steps, Nvar 3, all zero."""
+    g = load_golden("readme_rc")
+    ckt = parseNetlist(golden_netlist(g))
+    res = simulateTRAN(ckt, backend=oracle_backend, as_lists=False)
+    run = g["runs"][0]
+    assert len(res["times"]) == run["npoints"] == 10001
+    assert [res["times"][0], res["times"][1], res["times"][-1]] == run["times_first_last"]
+    assert list(res["nodeVoltages"]) == run["keysV"] and list(res["elementCurrents"]) == run["keysI"]
+    assert all(not np.any(v) for v in res["nodeVoltages"].values())
+
+
+def test_svg_snapshots(oracle_backend):
+    """Oracle-independent cross-check: the reference's five committed SVG snapshots (11 series)."""
+    svg = json.load(open(os.path.join(GOLD, "svg_series.json")))
+    n_series = 0
+    for snap, rec in svg.items():
+        g = load_golden(rec["netlist"])
+        ckt = parseNetlist(golden_netlist(g))
+        res = simulateTRAN(ckt, backend=oracle_backend, as_lists=False)
+        byupper = {k.upper(): v for k, v in res["nodeVoltages"].items()}
+        for label, series in rec["series"].items():
+            node = label[2:-1].upper()
+            got = byupper[node]
+            assert len(got) == len(series)
+            # y printed to 6 decimals: half a quantum + slack
+            assert np.max(np.abs(got - np.array(series))) <= 0.6 * rec["quantum"], (snap, label)
+            n_series += 1
+    assert n_series == 11
+
+
+def test_reference_test_thresholds(oracle_backend):
+    """Numeric pins of switch-vt-vh.test.ts:33-34,61-70 and vswitch-pwl.test.ts:58-76."""
+    g = load_golden("switch_vt_vh")
+    ckt = parseNetlist(golden_netlist(g))
+    m = ckt.S[0].model
+    assert abs(m.Von - 2.55) < 5e-3 and abs(m.Voff - 2.45) < 5e-3
+    res = simulateTRAN(ckt, backend=oracle_backend, as_lists=False)
+    t = np.array(res["times"])
+    v = res["nodeVoltages"]["N2"]
+    s = lambda x: v[np.argmin(np.abs(t - x))]  # noqa: E731
+    assert s(0.0002) > 4.9 and s(0.0007) < 0.1 and s(0.0012) > 4.9 and s(0.0017) < 0.1
+    g = load_golden("vswitch_pwl")
+    ckt = parseNetlist(golden_netlist(g))
+    res = simulateTRAN(ckt, backend=oracle_backend, as_lists=False)
+    assert len(res["times"]) == 1001  # dt defaulted -> 1000 steps
+
+
+def test_timestep_rounding():
+    """same double ops in the same order as simulateTRAN.ts:14-19."""
+    from oracle import pyoracle
+    for dt_req, tstop, want in [(1e-6, 0.1, 100001), (1e-6, 1e-2, 10000), (0.0, 0.01, 1000), (3e-6, 1e-6, 1),
+                                (0.3e-6, 1e-6, 4), (1e-7, 2e-5, 201), (0.1 * 1e-6, 20 * 1e-6, 200)]:
+        dt, steps = abi.computeEffectiveTimeStep(dt_req, tstop)
+        assert steps == want, (dt_req, tstop, steps)
+        assert pyoracle.timestep(dt_req, tstop) == (dt, steps)

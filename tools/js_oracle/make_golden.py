@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REFERENCE's own TRAN path (type-erased, Node 12).
+
+TEST INFRASTRUCTURE ONLY; runs only in the build container (needs /root/reference and node).
+  1. erase_types.py writes type-erased twins of the reference's 15 TRAN-path files into a
+     mkdtemp scratch directory (deleted at exit; never inside the repo);
+  2. driver.mjs imports the reference's parseNetlist + simulateTRAN from there and dumps results;
+  3. this script stores *numbers only* under tests/golden/: full results for small circuits,
+     node subsets + step snapshots + sha256 of the full step-major f64 arrays for large ones.
+
+Usage: python3 tools/js_oracle/make_golden.py [--only NAME ...] [--long]
+"""
+import argparse
+import hashlib
+import json
+import os
+import shutil
+import struct
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+GOLD = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+from spicey_amd import synth  # noqa: E402
+
+NODE = ["node", "--harmony-nullish", "--harmony-optional-chaining", "--max-old-space-size=16000"]
+
+# name -> (netlist file, repeat)
+SMALL = {
+    "readme_rc": 1, "two_probes": 2, "transient01": 1, "case_insensitive": 1, "switch_vt_vh": 1,
+    "vswitch_pwl": 1, "diode_switch": 2, "boost_probe": 1, "bridge_rectifier": 1, "lc_tank": 1,
+    "relay_osc": 1, "half_bridge": 2, "units_title": 1, "float_cap": 1, "steps_round": 1,
+    "err_singular": 1, "err_vloop": 1,
+}
+# name -> generator spec
+SYNTH = {
+    "ladder20": ("rc_ladder", dict(n=20, seed=1, tran=".tran 1e-6 5e-5")),
+    "dchain20": ("diode_chain", dict(n=20, seed=2, tran=".tran 1e-6 5e-5")),
+    "mesh6": ("rcd_mesh", dict(rows=6, seed=3, tran=".tran 1e-6 4e-5")),
+    "mesh9x5": ("rcd_mesh", dict(rows=9, cols=5, seed=7, tran=".tran 1e-6 3e-5")),
+}
+LARGE = {
+    # 200-step prefixes of configs 2/3 and a mesh slice of config 5
+    "rc1000_200": ("rc_ladder", dict(n=1000, seed=1, tran=".tran 1e-06 0.00019999999999999998")),
+    "dchain1000_200": ("diode_chain", dict(n=1000, seed=2, tran=".tran 1e-06 0.00019999999999999998")),
+    "mesh20_30": ("rcd_mesh", dict(rows=20, seed=3, tran=".tran 1e-6 3e-5")),
+}
+LONG = {
+    # full BASELINE configs 2/3: 10001 points, ~7 min each on the reference JS path
+    "rc1000_full": ("rc_ladder", dict(n=1000, seed=1, tran=".tran 1e-6 1e-2")),
+    "dchain1000_full": ("diode_chain", dict(n=1000, seed=2, tran=".tran 1e-6 1e-2")),
+}
+
+
+def run_driver(root, netlist_text, repeat=1):
+    with tempfile.TemporaryDirectory(prefix="spicey_gold_") as td:
+        cir = os.path.join(td, "in.cir")
+        out = os.path.join(td, "out.json")
+        with open(cir, "w") as f:
+            f.write(netlist_text)
+        subprocess.run(NODE + [os.path.join(HERE, "driver.mjs"), root, cir, out, str(repeat)], check=True)
+        with open(out) as f:
+            return json.load(f)
+
+
+def _f(v):
+    return float(v) if isinstance(v, str) else v
+
+
+def sha_step_major(series_by_key, keys, nsteps):
+    h = hashlib.sha256()
+    cols = [[_f(x) for x in series_by_key[k]] for k in keys]
+    for s in range(nsteps):
+        h.update(struct.pack("<%dd" % len(cols), *[c[s] for c in cols]))
+    return h.hexdigest()
+
+
+def summarise_large(res, name):
+    run = res["runs"][0]
+    n = len(run["times"])
+    keysV, keysI = run["keysV"], run["keysI"]
+    pick_nodes = [k for i, k in enumerate(keysV) if i in (0, 1, 2, 9, 49, 99, 126, 249, 499, 749, 998, 999, len(keysV) - 1)]
+    pick_steps = sorted(set(s for s in (0, 1, 2, 3, 10, 50, 100, 150, n // 2, n - 2, n - 1) if 0 <= s < n))
+    pick_elems = [k for i, k in enumerate(keysI) if i % max(1, len(keysI) // 12) == 0]
+    out = {k: res[k] for k in ("nodes", "probes", "counts", "tranSpec")}
+    out["summary"] = True
+    out["ms"] = run["ms"]
+    out["npoints"] = n
+    out["keysV"], out["keysI"] = keysV, keysI
+    out["times_first_last"] = [run["times"][0], run["times"][1], run["times"][-1]]
+    out["V_nodes"] = {k: run["V"][k] for k in pick_nodes}
+    out["V_steps"] = {str(s): [run["V"][k][s] for k in keysV] for s in pick_steps}
+    out["I_elems"] = {k: run["I"][k] for k in pick_elems}
+    out["I_steps"] = {str(s): [run["I"][k][s] for k in keysI] for s in pick_steps}
+    out["sumV_last"] = sum(run["V"][k][-1] for k in keysV)
+    out["sha256_V"] = sha_step_major(run["V"], keysV, n)
+    out["sha256_I"] = sha_step_major(run["I"], keysI, n)
+    out["state"] = run["state"]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*")
+    ap.add_argument("--long", action="store_true", help="also run the two 10001-point configs (~15 min)")
+    args = ap.parse_args()
+    root = tempfile.mkdtemp(prefix="spicey_oracle_")
+    try:
+        subprocess.run([sys.executable, os.path.join(HERE, "erase_types.py"), root], check=True)
+        want = lambda n: not args.only or n in args.only  # noqa: E731
+        for name, rep in SMALL.items():
+            if not want(name):
+                continue
+            text = open(os.path.join(GOLD, "netlists", name + ".cir")).read()
+            res = run_driver(root, text, rep)
+            res["netlist_file"] = f"netlists/{name}.cir"
+            if name == "readme_rc":  # 10001 x all-zero: keep a compact summary
+                run = res["runs"][0]
+                assert all(v == 0 for k in run["keysV"] for v in run["V"][k])
+                assert all(_f(v) == 0 for k in run["keysI"] for v in run["I"][k])
+                res["runs"] = [{"ms": run["ms"], "npoints": len(run["times"]), "keysV": run["keysV"], "keysI": run["keysI"],
+                                "times_first_last": [run["times"][0], run["times"][1], run["times"][-1]],
+                                "all_zero": True, "state": run["state"]}]
+            json.dump(res, open(os.path.join(GOLD, name + ".json"), "w"))
+            print(name, "error=" + repr(res.get("error")), [r and r.get("ms") for r in res.get("runs", [])])
+        for name, (gen, kw) in SYNTH.items():
+            if not want(name):
+                continue
+            res = run_driver(root, getattr(synth, gen)(**kw), 1)
+            res["generator"] = [gen, kw]
+            json.dump(res, open(os.path.join(GOLD, name + ".json"), "w"))
+            print(name, res.get("error"), res["runs"][0]["ms"])
+        big = dict(LARGE)
+        if args.long:
+            big.update(LONG)
+        for name, (gen, kw) in big.items():
+            if not want(name) or (name in LONG and not args.long):
+                continue
+            res = run_driver(root, getattr(synth, gen)(**kw), 1)
+            out = summarise_large(res, name)
+            out["generator"] = [gen, kw]
+            json.dump(out, open(os.path.join(GOLD, name + ".json"), "w"))
+            print(name, out["ms"], "ms", out["npoints"], "points", out["sha256_V"])
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
