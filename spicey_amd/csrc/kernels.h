@@ -1,0 +1,12 @@
+// kernels.h — host-callable launchers of kernels.hip
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+
+#include "program.h"
+
+#define SPICEY_LDS_MAX 163840  // 160 KiB per CU on MI355X (MI355X_MICROARCH.md "Chip-level parameters")
+
+size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds);
+size_t spicey_gw_doubles_per_wg(const SpiceyProg &P, int K);
+hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bool lds, int grid, int threads, hipStream_t st);

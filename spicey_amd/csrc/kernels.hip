@@ -1,0 +1,97 @@
+// kernels.hip — gfx950 kernels of the transient solver.
+//
+// spicey_tran_kernel<K, LDS>: ONE persistent workgroup per K instances runs the complete transient
+// (/root/reference/lib/analysis/simulateTRAN.ts:146-238) — time loop, switch iteration, stamping,
+// sparse LU with fused forward elimination, backward substitution, recording and state update —
+// with the matrix, right-hand side and element state resident in LDS (160 KB/CU on MI355X).
+// HBM sees only the result stream (coalesced 8*n_out / 8*n_cur bytes per step) and the L2-resident
+// program + per-instance static values.  The phase bodies live in tran_exec.h.
+//
+// LDS = false is the capacity fallback (circuits whose L+U does not fit 160 KB): same program, the
+// workspace lives in global memory (L2).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "tran_exec.h"
+
+namespace {
+
+struct GpuExec {
+  __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
+  template <class F>
+  __device__ __forceinline__ void phase(F f) {
+    f((int)threadIdx.x);
+    __syncthreads();
+  }
+};
+
+template <int K, bool LDS>
+__global__ void __launch_bounds__(1024) spicey_tran_kernel(SpiceyProg P, SpiceyRun R) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  WgCtx<K> c;
+  const int wg = (int)blockIdx.x;
+  const size_t nW = (size_t)P.nW * K, nU = (size_t)P.nU * K, nG = (size_t)P.nGdyn * K;
+  if (LDS) {
+    c.W = (double *)smem;
+    c.u = c.W + nW;
+    c.gd = c.u + nU;
+    c.ison = (int32_t *)(c.gd + nG);
+    c.flags = c.ison + (size_t)P.nS * K;
+  } else {
+    const size_t stride = nW + nU + nG + (((size_t)P.nS * K + 1) >> 1);
+    c.W = R.gW + (size_t)wg * stride;
+    c.u = c.W + nW;
+    c.gd = c.u + nU;
+    c.ison = (int32_t *)(c.gd + nG);
+    c.flags = (int32_t *)smem;
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int in = wg * K + k;
+    c.valid[k] = in < R.n_inst;
+    c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
+  }
+  GpuExec ex;
+  spicey_tran_run<K>(ex, P, R, c, wg);
+}
+
+template <int K, bool LDS>
+hipError_t launch_t(const SpiceyProg &P, const SpiceyRun &R, int grid, int threads, size_t lds, hipStream_t st) {
+  auto kern = spicey_tran_kernel<K, LDS>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, R);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds) {
+  if (!lds) return 64;
+  size_t b = ((size_t)P.nW + P.nU + P.nGdyn) * K * sizeof(double) + ((size_t)P.nS * K + 4) * sizeof(int32_t);
+  return (b + 15) & ~size_t(15);
+}
+
+size_t spicey_gw_doubles_per_wg(const SpiceyProg &P, int K) {
+  return ((size_t)P.nW + P.nU + P.nGdyn) * K + (((size_t)P.nS * K + 1) >> 1);
+}
+
+hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bool lds, int grid, int threads, hipStream_t st) {
+  const size_t bytes = spicey_lds_bytes(P, K, lds);
+  if (lds) {
+    switch (K) {
+      case 1: return launch_t<1, true>(P, R, grid, threads, bytes, st);
+      case 2: return launch_t<2, true>(P, R, grid, threads, bytes, st);
+      case 4: return launch_t<4, true>(P, R, grid, threads, bytes, st);
+    }
+  } else {
+    switch (K) {
+      case 1: return launch_t<1, false>(P, R, grid, threads, bytes, st);
+      case 2: return launch_t<2, false>(P, R, grid, threads, bytes, st);
+      case 4: return launch_t<4, false>(P, R, grid, threads, bytes, st);
+    }
+  }
+  return hipErrorInvalidValue;
+}

@@ -1,0 +1,109 @@
+// program.h — the device-side "program": everything the symbolic phase hands to the kernels.
+//
+// The reference re-discovers the matrix structure every iteration (dense zero fill,
+// simulateTRAN.ts:152-153; pivot search, solveReal.ts:15-34).  Here the structure is compiled
+// ONCE per topology into flat index arrays; the per-timestep kernel only interprets them.
+//
+// Index spaces
+//   W index      unified workspace: [0, nLU) = entries of L+U (row-major CSR order of the permuted
+//                matrix), [nLU, nLU+n) = right-hand side / solution x' in pivot order
+//   u index      source vector: [0,nC) vPrev | [nC,nC+nL) iPrev | [..,+nV) V(t) | [..,+nD) diode ieq
+//   gdyn index   [0,nS) switch conductances | [nS,nS+nD) diode gd
+//   gstat index  [0,nR) 1/R | [nR,nR+nC) C/dt | [..,+nL) dt/L | last = 1.0 (voltage-source +-1)
+// Signs are folded into the top bit of an index (SPICEY_NEG).
+#pragma once
+#include <stdint.h>
+
+#define SPICEY_NEG 0x80000000u
+#define SPICEY_IDX(x) ((x)&0x7fffffffu)
+#define SPICEY_EPS 1e-15
+#define SPICEY_VT300 0.02585
+#define SPICEY_MAX_ITER 20
+
+// flags in the top bits of an update-task target
+#define SPICEY_TGT_RECIP 0x80000000u  // diagonal becomes final in this task: store 1/pivot, check singularity
+#define SPICEY_TGT_PAD 0x7fffffffu    // padding lane of a slice
+
+struct SpiceySlice {
+  uint32_t off;  // offset (in uint32 words) of the slice's index block inside `pairs`
+  uint32_t len;  // longest task of the slice (number of products)
+};
+
+// All pointers are device pointers (or host pointers inside the test emulator).
+struct SpiceyProg {
+  int32_t n;       // unknowns = n_nodes + nV
+  int32_t nLU;     // entries of L+U
+  int32_t nW;      // nLU + n
+  int32_t nLevels; // etree height
+  int32_t nR, nC, nL, nV, nS, nD;
+  int32_t nU;      // nC+nL+nV+nD
+  int32_t nGdyn;   // nS+nD
+  int32_t nGstat;  // nR+nC+nL+1
+  int32_t nOut, nCur;
+
+  // --- prologue: static part of every L+U entry (CSR over entries, gstat index | sign)
+  const uint32_t *stat_ptr;  // [nLU+1]
+  const uint32_t *stat_idx;  // [...]
+  const uint8_t *ent_flag;   // [nLU] bit0: leaf diagonal (no update reaches it) ; bit1: has dynamic stamps
+
+  // --- phase B: dynamic stamps (switches, diodes) and right-hand side
+  int32_t nDynEnt;
+  const uint32_t *dyn_ent;  // [nDynEnt] entry id | SPICEY_TGT_RECIP if leaf diagonal
+  const uint32_t *dyn_ptr;  // [nDynEnt+1]
+  const uint32_t *dyn_idx;  // gdyn index | sign
+  const uint32_t *rhs_ptr;  // [n+1] per pivot-order row
+  const uint32_t *rhs_idx;  // [nRhsIdx] u index | sign
+  const uint32_t *rhs_cof;  // [nRhsIdx] gstat index of the coefficient (C/dt for capacitors, the 1.0 slot otherwise)
+  int32_t nRhsIdx;
+
+  // --- factor (fused forward elimination): per level, wave-sized slices of update tasks
+  const uint32_t *lvl_slice;    // [nLevels+1] first slice of each level (last level has none)
+  const SpiceySlice *upd_slice; // [nUpdSlices]
+  const uint32_t *upd_tgt;      // [nUpdSlices*64] W index | SPICEY_TGT_RECIP, or SPICEY_TGT_PAD
+  const uint32_t *upd_cnt;      // [nUpdSlices*64]
+  const uint32_t *upd_pairs;    // per slice: [len][3][64]  (L entry, pivot diagonal, U entry)
+  int32_t nUpdSlices;
+
+  // --- backward substitution: per level (executed top level first)
+  const uint32_t *bk_lvl_slice; // [nLevels+1]
+  const SpiceySlice *bk_slice;  // [nBkSlices]
+  const uint32_t *bk_x;         // [nBkSlices*64] W index of x'[k], or SPICEY_TGT_PAD
+  const uint32_t *bk_d;         // [nBkSlices*64] W index of the pivot's (reciprocal) diagonal
+  const uint32_t *bk_cnt;       // [nBkSlices*64]
+  const uint32_t *bk_pairs;     // per slice: [len][2][64]  (U entry, W index of x'[b])
+  int32_t nBkSlices;
+
+  // --- elements: terminal positions in W (x' slots), -1 = ground
+  const int32_t *R_a, *R_b, *C_a, *C_b, *L_a, *L_b, *S_a, *S_b, *S_cp, *S_cn, *D_a, *D_b;
+  const int32_t *V_x;   // [nV] W index of the branch current
+  const int32_t *out_x; // [nOut] W index of each recorded node voltage
+};
+
+// Per-run, per-instance data (device pointers; instance-major arrays)
+struct SpiceyRun {
+  int32_t n_inst;
+  int32_t want_currents;
+  int64_t steps;
+  double dt;
+  // parameters
+  const double *R_val, *C_val, *L_val;             // [n_inst][n*]
+  const double *S_ron, *S_roff, *S_von, *S_voff;   // [n_inst][nS]
+  const double *D_is, *D_n;                        // [n_inst][nD]
+  // state (in: entering the run, out: leaving it)
+  double *C_vprev, *L_iprev, *D_vdprev;            // [n_inst][n*]
+  int32_t *S_ison;                                 // [n_inst][nS]
+  // per-run workspaces written by the prologue
+  double *gstat;  // [n_inst][nGstat]
+  double *statv;  // [n_inst][nLU]  static part of every entry (pre-inverted for static leaf diagonals)
+  double *rcoef;  // [n_inst][nRhsIdx] coefficient of every right-hand-side contribution
+  // global-memory fallback for W/u/gdyn when LDS is too small: [n_workgroups][...]
+  double *gW;
+  // io
+  const double *src;  // [steps+1][nV]
+  double *out_v;      // [n_inst][steps+1][nOut]
+  double *out_i;      // [n_inst][steps+1][nCur] or null
+  int32_t *iters;     // [n_inst][steps+1] or null
+  // status: [n_workgroups][4] = {code, inst, step, iter}; solve counts [n_workgroups]
+  int32_t *status;
+  unsigned long long *solves;
+};

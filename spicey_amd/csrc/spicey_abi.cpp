@@ -1,0 +1,330 @@
+// spicey_abi.cpp — the C-ABI of include/spicey_hip.h: handle management, uploads, launches.
+// Host code only (HIP runtime API); the kernels are in kernels.hip, the symbolic phase in
+// symbolic.cpp.  There is NO CPU solve path in this library: without a HIP device every entry
+// point that would compute returns SPICEY_ERR_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spicey_hip.h"
+#include "kernels.h"
+#include "symbolic.h"
+
+struct SpiceyHandle {
+  HostProgram hp;
+  SpiceyProg dprog{};
+  SpiceyOptions opt{};
+  int n_inst = 0, n_nodes = 0;
+  int K = 1, T = 256, grid = 1;
+  bool lds = true;
+  size_t lds_bytes = 0;
+  int device = 0;
+  int64_t algo_bytes = 0;
+  // device memory
+  void *d_blob = nullptr;
+  double *d_R = nullptr, *d_C = nullptr, *d_L = nullptr, *d_Sron = nullptr, *d_Sroff = nullptr, *d_Svon = nullptr, *d_Svoff = nullptr,
+         *d_Dis = nullptr, *d_Dn = nullptr;
+  double *d_Cv = nullptr, *d_Li = nullptr, *d_Dv = nullptr;
+  int32_t *d_Son = nullptr;
+  double *d_gstat = nullptr, *d_statv = nullptr, *d_rcoef = nullptr, *d_gW = nullptr;
+  int32_t *d_status = nullptr;
+  unsigned long long *d_solves = nullptr;
+  hipStream_t stream = nullptr;  // owned stream for spicey_run
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool pending = false;
+  int64_t last_solves = 0;
+  double last_ms = 0.0;
+  std::string err;
+};
+
+static std::string g_err;
+
+#define HIPCHK(h, call)                                                                 \
+  do {                                                                                  \
+    hipError_t e__ = (call);                                                            \
+    if (e__ != hipSuccess) {                                                            \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                    \
+      return SPICEY_ERR_HIP;                                                            \
+    }                                                                                   \
+  } while (0)
+
+template <class T>
+static int32_t upload(SpiceyHandle *h, T **dst, const T *src, size_t count) {
+  *dst = nullptr;
+  size_t bytes = (count ? count : 1) * sizeof(T);
+  HIPCHK(h, hipMalloc((void **)dst, bytes));
+  if (count && src) HIPCHK(h, hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  else HIPCHK(h, hipMemset(*dst, 0, bytes));
+  return SPICEY_OK;
+}
+
+extern "C" const char *spicey_version(void) { return "spicey_hip abi1 gfx950 (persistent LDS-resident sparse-LU transient kernel)"; }
+
+extern "C" const char *spicey_last_error(SpiceyHandle *h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+extern "C" void spicey_destroy(SpiceyHandle *h) {
+  if (!h) return;
+  if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
+  void *ptrs[] = {h->d_blob, h->d_R, h->d_C, h->d_L, h->d_Sron, h->d_Sroff, h->d_Svon, h->d_Svoff, h->d_Dis, h->d_Dn, h->d_Cv,
+                  h->d_Li, h->d_Dv, h->d_Son, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_status, h->d_solves};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+static int pick_threads(const HostProgram &hp) {
+  // widest phase decides: one lane per task, one or two tasks per lane
+  const int n = hp.hdr.n;
+  if (n <= 48) return 64;
+  if (n <= 160) return 128;
+  if (n <= 400) return 256;
+  if (n <= 4000) return 512;
+  return 1024;
+}
+
+extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *opt, SpiceyHandle **out) {
+  if (!out) { g_err = "null out pointer"; return SPICEY_ERR_BAD_DESC; }
+  *out = nullptr;
+  SpiceyHandle *h = new SpiceyHandle();
+  if (opt) h->opt = *opt;
+  std::string err;
+  int32_t rc = spicey_build_program(desc, h->hp, err);
+  if (rc != SPICEY_OK) {
+    g_err = err;
+    delete h;
+    return rc;
+  }
+  h->n_inst = desc->n_inst;
+  h->n_nodes = desc->n_nodes;
+  h->algo_bytes = spicey_algorithmic_bytes(desc, h->hp.nnzA, h->hp.hdr.nLU);
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_err = "no HIP device: libspicey_hip has no CPU path";
+    delete h;
+    return SPICEY_ERR_NO_DEVICE;
+  }
+  h->device = h->opt.device;
+  if (h->device < 0 || h->device >= ndev) {
+    g_err = "device ordinal out of range";
+    delete h;
+    return SPICEY_ERR_BAD_DESC;
+  }
+  auto fail = [&](int32_t code) {
+    g_err = h->err;
+    spicey_destroy(h);
+    return code;
+  };
+  if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return fail(SPICEY_ERR_HIP); }
+  int ncu = 256;
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+
+  // ---- geometry: instances per workgroup, threads, LDS or global workspace --------------------
+  const SpiceyProg &P = h->hp.hdr;
+  int K = h->opt.inst_per_wg;
+  const bool want_lds = !h->opt.force_global;
+  if (K != 0 && K != 1 && K != 2 && K != 4) { h->err = "inst_per_wg must be 0, 1, 2 or 4"; return fail(SPICEY_ERR_BAD_DESC); }
+  if (P.nS > 0) K = 1;  // the switch iteration count is per instance: no interleaving
+  if (K == 0) {
+    K = 1;
+    // interleave two instances when that still leaves every CU a workgroup and fits LDS
+    if (want_lds && h->n_inst >= 2 * ncu && spicey_lds_bytes(P, 2, true) <= SPICEY_LDS_MAX) K = 2;
+  }
+  if (K > h->n_inst) K = 1;
+  h->lds = want_lds && spicey_lds_bytes(P, K, true) <= SPICEY_LDS_MAX;
+  if (!h->lds && want_lds && K > 1) {
+    K = 1;
+    h->lds = spicey_lds_bytes(P, 1, true) <= SPICEY_LDS_MAX;
+  }
+  h->K = K;
+  h->T = h->opt.threads > 0 ? h->opt.threads : pick_threads(h->hp);
+  if (h->T > 1024 || (h->T & 63)) { h->err = "threads must be a multiple of 64, <= 1024"; return fail(SPICEY_ERR_BAD_DESC); }
+  h->grid = (h->n_inst + K - 1) / K;
+  h->lds_bytes = spicey_lds_bytes(P, K, h->lds);
+
+  // ---- uploads -----------------------------------------------------------------------------------
+  const size_t ni = (size_t)h->n_inst;
+  if (hipMalloc(&h->d_blob, h->hp.blob.size()) != hipSuccess) { h->err = "hipMalloc(program) failed"; return fail(SPICEY_ERR_HIP); }
+  if (hipMemcpy(h->d_blob, h->hp.blob.data(), h->hp.blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    h->err = "hipMemcpy(program) failed";
+    return fail(SPICEY_ERR_HIP);
+  }
+  h->dprog = h->hp.bind(h->d_blob);
+#define UP(dst, src, cnt) \
+  if ((rc = upload(h, &h->dst, desc->src, (cnt))) != SPICEY_OK) return fail(rc)
+  UP(d_R, R_val, ni * P.nR);
+  UP(d_C, C_val, ni * P.nC);
+  UP(d_L, L_val, ni * P.nL);
+  UP(d_Sron, S_ron, ni * P.nS);
+  UP(d_Sroff, S_roff, ni * P.nS);
+  UP(d_Svon, S_von, ni * P.nS);
+  UP(d_Svoff, S_voff, ni * P.nS);
+  UP(d_Dis, D_is, ni * P.nD);
+  UP(d_Dn, D_n, ni * P.nD);
+  UP(d_Cv, C_vprev, ni * P.nC);
+  UP(d_Li, L_iprev, ni * P.nL);
+  UP(d_Dv, D_vdprev, ni * P.nD);
+  UP(d_Son, S_ison, ni * P.nS);
+#undef UP
+  const double *nodbl = nullptr;
+  if ((rc = upload(h, &h->d_gstat, nodbl, ni * P.nGstat)) != SPICEY_OK) return fail(rc);
+  if ((rc = upload(h, &h->d_statv, nodbl, ni * P.nLU)) != SPICEY_OK) return fail(rc);
+  if ((rc = upload(h, &h->d_rcoef, nodbl, ni * (size_t)(P.nRhsIdx + 1))) != SPICEY_OK) return fail(rc);
+  if (!h->lds)
+    if ((rc = upload(h, &h->d_gW, nodbl, (size_t)h->grid * spicey_gw_doubles_per_wg(P, K))) != SPICEY_OK) return fail(rc);
+  const int32_t *noint = nullptr;
+  if ((rc = upload(h, &h->d_status, noint, (size_t)h->grid * 4)) != SPICEY_OK) return fail(rc);
+  const unsigned long long *noull = nullptr;
+  if ((rc = upload(h, &h->d_solves, noull, (size_t)h->grid)) != SPICEY_OK) return fail(rc);
+  if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    h->err = "stream/event creation failed";
+    return fail(SPICEY_ERR_HIP);
+  }
+  *out = h;
+  return SPICEY_OK;
+}
+
+extern "C" int32_t spicey_get_info(SpiceyHandle *h, SpiceyInfo *info) {
+  if (!h || !info) return SPICEY_ERR_BAD_DESC;
+  memset(info, 0, sizeof(*info));
+  info->n_var = h->hp.hdr.n;
+  info->nnz_a = h->hp.nnzA;
+  info->nnz_lu = h->hp.hdr.nLU;
+  info->n_levels = h->hp.hdr.nLevels;
+  info->threads = h->T;
+  info->inst_per_wg = h->K;
+  info->lds_bytes = h->lds ? (int32_t)h->lds_bytes : 0;
+  info->n_cur = h->hp.hdr.nCur;
+  info->n_out = h->hp.hdr.nOut;
+  info->n_workgroups = h->grid;
+  info->program_bytes = (int64_t)h->hp.blob.size();
+  info->algorithmic_bytes_solve = h->algo_bytes;
+  return SPICEY_OK;
+}
+
+extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, const double *d_src_table, double *d_out_v,
+                                     double *d_out_i, int32_t *d_iters, void *stream) {
+  if (!h) return SPICEY_ERR_BAD_DESC;
+  if (steps < 0 || !d_out_v || (h->hp.hdr.nV > 0 && !d_src_table)) { h->err = "bad run arguments"; return SPICEY_ERR_BAD_DESC; }
+  if (h->hp.structurally_singular) {
+    h->err = "singular at inst 0 step 0 iter 0 (structurally singular matrix)";
+    return SPICEY_ERR_SINGULAR;
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  SpiceyRun R{};
+  R.n_inst = h->n_inst;
+  R.want_currents = d_out_i != nullptr;
+  R.steps = steps;
+  R.dt = dt;
+  R.R_val = h->d_R; R.C_val = h->d_C; R.L_val = h->d_L;
+  R.S_ron = h->d_Sron; R.S_roff = h->d_Sroff; R.S_von = h->d_Svon; R.S_voff = h->d_Svoff;
+  R.D_is = h->d_Dis; R.D_n = h->d_Dn;
+  R.C_vprev = h->d_Cv; R.L_iprev = h->d_Li; R.D_vdprev = h->d_Dv; R.S_ison = h->d_Son;
+  R.gstat = h->d_gstat; R.statv = h->d_statv; R.rcoef = h->d_rcoef; R.gW = h->d_gW;
+  R.src = d_src_table; R.out_v = d_out_v; R.out_i = d_out_i; R.iters = d_iters;
+  R.status = h->d_status; R.solves = h->d_solves;
+  HIPCHK(h, hipEventRecord(h->ev0, st));
+  HIPCHK(h, spicey_launch_tran(h->dprog, R, h->K, h->lds, h->grid, h->T, st));
+  HIPCHK(h, hipEventRecord(h->ev1, st));
+  h->pending = true;
+  h->last_stream = st;
+  return SPICEY_OK;
+}
+
+extern "C" int32_t spicey_sync(SpiceyHandle *h) {
+  if (!h) return SPICEY_ERR_BAD_DESC;
+  if (!h->pending) return SPICEY_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->last_stream));
+  h->pending = false;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_ms = ms;
+  std::vector<int32_t> status((size_t)h->grid * 4);
+  std::vector<unsigned long long> solves((size_t)h->grid);
+  HIPCHK(h, hipMemcpy(status.data(), h->d_status, status.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(solves.data(), h->d_solves, solves.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  h->last_solves = 0;
+  for (auto s : solves) h->last_solves += (int64_t)s;
+  // earliest failure wins (the reference throws at the first singular solve)
+  int best = -1;
+  for (int g = 0; g < h->grid; g++)
+    if (status[(size_t)g * 4] != 0 && (best < 0 || status[(size_t)g * 4 + 2] < status[(size_t)best * 4 + 2])) best = g;
+  if (best >= 0) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "singular at inst %d step %d iter %d", status[(size_t)best * 4 + 1], status[(size_t)best * 4 + 2],
+             status[(size_t)best * 4 + 3]);
+    h->err = buf;
+    return SPICEY_ERR_SINGULAR;
+  }
+  return SPICEY_OK;
+}
+
+extern "C" int32_t spicey_run(SpiceyHandle *h, int64_t steps, double dt, const double *src_table, double *out_v, double *out_i,
+                              int32_t *iters) {
+  if (!h) return SPICEY_ERR_BAD_DESC;
+  if (steps < 0 || !out_v || (h->hp.hdr.nV > 0 && !src_table)) { h->err = "bad run arguments"; return SPICEY_ERR_BAD_DESC; }
+  if (h->hp.structurally_singular) {
+    h->err = "singular at inst 0 step 0 iter 0 (structurally singular matrix)";
+    return SPICEY_ERR_SINGULAR;
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  const SpiceyProg &P = h->hp.hdr;
+  const size_t np = (size_t)steps + 1, ni = (size_t)h->n_inst;
+  double *d_src = nullptr, *d_v = nullptr, *d_i = nullptr;
+  int32_t *d_it = nullptr;
+  int32_t rc = SPICEY_OK;
+  auto cleanup = [&]() {
+    if (d_src) (void)hipFree(d_src);
+    if (d_v) (void)hipFree(d_v);
+    if (d_i) (void)hipFree(d_i);
+    if (d_it) (void)hipFree(d_it);
+  };
+#define TRY(call)                                                        \
+  do {                                                                   \
+    hipError_t e__ = (call);                                             \
+    if (e__ != hipSuccess) {                                             \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e__);       \
+      cleanup();                                                         \
+      return SPICEY_ERR_HIP;                                             \
+    }                                                                    \
+  } while (0)
+  TRY(hipMalloc((void **)&d_src, std::max<size_t>(np * P.nV, 1) * sizeof(double)));
+  if (P.nV) TRY(hipMemcpyAsync(d_src, src_table, np * P.nV * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  TRY(hipMalloc((void **)&d_v, std::max<size_t>(ni * np * P.nOut, 1) * sizeof(double)));
+  if (out_i) TRY(hipMalloc((void **)&d_i, std::max<size_t>(ni * np * P.nCur, 1) * sizeof(double)));
+  if (iters) TRY(hipMalloc((void **)&d_it, ni * np * sizeof(int32_t)));
+  rc = spicey_run_device(h, steps, dt, d_src, d_v, d_i, d_it, h->stream);
+  if (rc == SPICEY_OK) rc = spicey_sync(h);
+  if (rc == SPICEY_OK) {
+    TRY(hipMemcpy(out_v, d_v, ni * np * P.nOut * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_i) TRY(hipMemcpy(out_i, d_i, ni * np * P.nCur * sizeof(double), hipMemcpyDeviceToHost));
+    if (iters) TRY(hipMemcpy(iters, d_it, ni * np * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+#undef TRY
+  cleanup();
+  return rc;
+}
+
+extern "C" int32_t spicey_get_state(SpiceyHandle *h, double *C_vprev, double *L_iprev, double *D_vdprev, int32_t *S_ison) {
+  if (!h) return SPICEY_ERR_BAD_DESC;
+  int32_t rc = spicey_sync(h);
+  if (rc != SPICEY_OK && rc != SPICEY_ERR_SINGULAR) return rc;
+  const SpiceyProg &P = h->hp.hdr;
+  const size_t ni = (size_t)h->n_inst;
+  if (C_vprev && P.nC) HIPCHK(h, hipMemcpy(C_vprev, h->d_Cv, ni * P.nC * sizeof(double), hipMemcpyDeviceToHost));
+  if (L_iprev && P.nL) HIPCHK(h, hipMemcpy(L_iprev, h->d_Li, ni * P.nL * sizeof(double), hipMemcpyDeviceToHost));
+  if (D_vdprev && P.nD) HIPCHK(h, hipMemcpy(D_vdprev, h->d_Dv, ni * P.nD * sizeof(double), hipMemcpyDeviceToHost));
+  if (S_ison && P.nS) HIPCHK(h, hipMemcpy(S_ison, h->d_Son, ni * P.nS * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return SPICEY_OK;
+}
+
+extern "C" int64_t spicey_last_solve_count(SpiceyHandle *h) { return h ? h->last_solves : 0; }
+extern "C" double spicey_last_kernel_ms(SpiceyHandle *h) { return h ? h->last_ms : 0.0; }

@@ -1,0 +1,683 @@
+// symbolic.cpp — host symbolic phase of the MI355X transient solver.
+//
+// Replaces what the reference redoes on every iteration (dense allocation simulateTRAN.ts:152-153,
+// partial-pivot search and row swaps solveReal.ts:15-34) by a ONE-TIME analysis per topology:
+//   1. MNA pattern from the element lists (stampAdmittanceReal.ts:3-29, stampVoltageSourceReal.ts:4-32)
+//   2. row matching for a zero-free diagonal: voltage-source branch rows have A[j][j] = 0
+//      (stampVoltageSourceReal.ts:26-31); the reference relies on partial pivoting, here the branch
+//      equation is matched to one of its node columns (entry +-1) once, statically
+//   3. nested-dissection ordering by BFS level-structure separators: short elimination tree
+//      (log2 N levels on a ladder = cyclic reduction) so that each level is one parallel GPU phase
+//   4. symbolic LU on the symmetrised pattern, elimination-tree levels
+//   5. compilation into gather-form task lists (no atomics, deterministic summation order):
+//      static/dynamic stamp lists, right-hand-side lists, per-level update tasks (factorisation with
+//      the forward elimination fused in as an extra column), per-level backward-substitution tasks.
+#include "symbolic.h"
+
+#include <algorithm>
+#include <cstring>
+#include <functional>
+#include <numeric>
+
+namespace {
+
+typedef std::vector<std::vector<int>> Adj;
+
+void sort_unique(std::vector<int> &v) {
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. maximum transversal (MC21-style augmenting DFS, iterative).  rows_of_col[c] lists candidate
+// rows (preferred first).  Returns row_of_col[] or fails.
+bool max_transversal(int n, const Adj &rows_of_col, std::vector<int> &row_of_col) {
+  std::vector<int> col_of_row(n, -1);
+  row_of_col.assign(n, -1);
+  // cheap pass: diagonal first, then any free row
+  for (int c = 0; c < n; c++)
+    for (int r : rows_of_col[c])
+      if (r == c && col_of_row[r] < 0) {
+        row_of_col[c] = r;
+        col_of_row[r] = c;
+        break;
+      }
+  for (int c = 0; c < n; c++) {
+    if (row_of_col[c] >= 0) continue;
+    for (int r : rows_of_col[c])
+      if (col_of_row[r] < 0) {
+        row_of_col[c] = r;
+        col_of_row[r] = c;
+        break;
+      }
+  }
+  std::vector<int> visited(n, -1), stack_c, stack_i;
+  for (int c0 = 0; c0 < n; c0++) {
+    if (row_of_col[c0] >= 0) continue;
+    // DFS over columns; path stored in stack_c with iterator positions stack_i
+    stack_c.assign(1, c0);
+    stack_i.assign(1, 0);
+    std::vector<int> path_row;  // row chosen at each depth
+    bool found = false;
+    while (!stack_c.empty()) {
+      int c = stack_c.back();
+      int &i = stack_i.back();
+      if (i == 0) {
+        // look for a free row first
+        for (int r : rows_of_col[c])
+          if (col_of_row[r] < 0) {
+            path_row.push_back(r);
+            found = true;
+            break;
+          }
+        if (found) break;
+      }
+      bool descended = false;
+      while (i < (int)rows_of_col[c].size()) {
+        int r = rows_of_col[c][i++];
+        if (visited[r] == c0) continue;
+        visited[r] = c0;
+        int c2 = col_of_row[r];
+        if (c2 < 0) continue;  // (handled above)
+        path_row.push_back(r);
+        stack_c.push_back(c2);
+        stack_i.push_back(0);
+        descended = true;
+        break;
+      }
+      if (!descended) {
+        stack_c.pop_back();
+        stack_i.pop_back();
+        if (!path_row.empty() && !stack_c.empty()) path_row.pop_back();
+      }
+    }
+    if (!found) return false;
+    // augment along the path: stack_c[d] takes path_row[d]
+    for (int d = (int)stack_c.size() - 1; d >= 0; d--) {
+      int c = stack_c[d], r = path_row[d];
+      row_of_col[c] = r;
+      col_of_row[r] = c;
+    }
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. nested dissection on an undirected graph.
+struct NDOrder {
+  const Adj &g;
+  int n;
+  std::vector<int> order;        // elimination order (list of vertices)
+  std::vector<int> owner;        // current sub-problem id of each vertex (-1 = already ordered)
+  std::vector<int> dist, queue_;
+  int next_id = 1;
+
+  explicit NDOrder(const Adj &g_) : g(g_), n((int)g_.size()), owner(g_.size(), 0), dist(g_.size(), -1) { order.reserve(n); }
+
+  // BFS inside sub-problem `id` from `s`; fills queue_ (visit order) and dist; returns eccentricity
+  int bfs(int s, int id) {
+    queue_.clear();
+    queue_.push_back(s);
+    dist[s] = 0;
+    size_t head = 0;
+    while (head < queue_.size()) {
+      int v = queue_[head++];
+      for (int w : g[v])
+        if (owner[w] == id && dist[w] < 0) {
+          dist[w] = dist[v] + 1;
+          queue_.push_back(w);
+        }
+    }
+    return dist[queue_.back()];
+  }
+  void clear_dist() {
+    for (int v : queue_) dist[v] = -1;
+  }
+  int sub_degree(int v, int id) const {
+    int d = 0;
+    for (int w : g[v]) d += owner[w] == id;
+    return d;
+  }
+
+  void run() {
+    // iterative over a work stack of sub-problems (vertex lists)
+    std::vector<std::vector<int>> work;
+    {
+      std::vector<int> all(n);
+      std::iota(all.begin(), all.end(), 0);
+      work.push_back(all);
+    }
+    // Sub-problems must be ordered so that separators come AFTER both halves.  Use a recursive
+    // lambda with an explicit depth guard instead of a work stack to keep that order simple.
+    std::function<void(std::vector<int> &, int)> rec = [&](std::vector<int> &verts, int depth) {
+      if (verts.empty()) return;
+      int id = next_id++;
+      for (int v : verts) owner[v] = id;
+      // split into connected components
+      std::vector<std::vector<int>> comps;
+      for (int v : verts) {
+        if (dist[v] >= 0) continue;
+        bfs(v, id);
+        comps.emplace_back(queue_);
+        // keep dist marks until all components are found
+        for (int w : queue_) dist[w] = 1 << 30;
+      }
+      for (int v : verts) dist[v] = -1;
+      if (comps.size() > 1) {
+        for (auto &c : comps) rec(c, depth + 1);
+        return;
+      }
+      std::vector<int> &S = comps[0];
+      if (S.size() <= 2 || depth > 200) {
+        leaf(S, id);
+        return;
+      }
+      // pseudo-peripheral start
+      int s = S[0], sd = sub_degree(S[0], id);
+      for (int v : S) {
+        int dg = sub_degree(v, id);
+        if (dg < sd) { sd = dg; s = v; }
+      }
+      int ecc = -1;
+      for (int it = 0; it < 8; it++) {
+        int e = bfs(s, id);
+        // candidate: min-degree vertex of the last level
+        int best = -1, bd = 1 << 30;
+        for (int i = (int)queue_.size() - 1; i >= 0 && dist[queue_[i]] == e; i--) {
+          int dg = sub_degree(queue_[i], id);
+          if (dg < bd) { bd = dg; best = queue_[i]; }
+        }
+        clear_dist();
+        if (e <= ecc) break;
+        ecc = e;
+        s = best;
+      }
+      int h = bfs(s, id);
+      if (h < 2) {
+        clear_dist();
+        leaf(S, id);
+        return;
+      }
+      // level sizes
+      std::vector<int> lsize(h + 1, 0);
+      for (int v : queue_) lsize[dist[v]]++;
+      int total = (int)S.size();
+      // choose the separator level: smallest level among those leaving >= 30 % on each side,
+      // falling back to the level where the cumulative count crosses one half
+      int m = -1, best_sz = 1 << 30, best_imb = 1 << 30, cum = 0, median = 1;
+      for (int l = 0; l <= h; l++) {
+        int below = cum, above = total - cum - lsize[l];
+        if (l >= 1 && l <= h - 1) {
+          const int imb = below > above ? below - above : above - below;
+          if (below * 10 >= total * 3 && above * 10 >= total * 3 &&
+              (lsize[l] < best_sz || (lsize[l] == best_sz && imb < best_imb))) {
+            best_sz = lsize[l];
+            best_imb = imb;
+            m = l;
+          }
+          if (cum * 2 < total) median = l;
+        }
+        cum += lsize[l];
+      }
+      if (m < 0) m = std::min(std::max(median, 1), h - 1);
+      std::vector<int> A, B, sep;
+      for (int v : queue_) {
+        int dv = dist[v];
+        if (dv < m) A.push_back(v);
+        else if (dv > m) B.push_back(v);
+        else {
+          bool touches = false;
+          for (int w : g[v])
+            if (owner[w] == id && dist[w] == m + 1) { touches = true; break; }
+          (touches ? sep : A).push_back(v);
+        }
+      }
+      clear_dist();
+      for (int v : sep) owner[v] = -2;  // removed from both halves
+      rec(A, depth + 1);
+      rec(B, depth + 1);
+      for (int v : sep) {
+        order.push_back(v);
+        owner[v] = -1;
+      }
+    };
+    rec(work[0], 0);
+  }
+
+  void leaf(std::vector<int> &S, int id) {
+    // small or unsplittable blob: ascending sub-degree, ties by vertex number
+    std::vector<std::pair<int, int>> key;
+    for (int v : S) key.emplace_back(sub_degree(v, id), v);
+    std::sort(key.begin(), key.end());
+    for (auto &kv : key) {
+      order.push_back(kv.second);
+      owner[kv.second] = -1;
+    }
+  }
+};
+
+struct EntryIndex {
+  // CSR of the permuted L+U pattern
+  std::vector<int> ptr, col;
+  int find(int r, int c) const {
+    auto b = col.begin() + ptr[r], e = col.begin() + ptr[r + 1];
+    auto it = std::lower_bound(b, e, c);
+    return (it != e && *it == c) ? (int)(it - col.begin()) : -1;
+  }
+};
+
+template <class T>
+size_t add_section(std::vector<uint8_t> &blob, std::vector<size_t> &offs, const std::vector<T> &v) {
+  size_t off = (blob.size() + 15) & ~size_t(15);
+  blob.resize(off + std::max<size_t>(v.size() * sizeof(T), 16));
+  if (!v.empty()) memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
+  offs.push_back(off);
+  return off;
+}
+
+// Pack variable-length tasks into wave-sized slices (tasks sorted by descending length so that a
+// slice's lanes have similar trip counts).  W = number of index words per product.
+template <int W>
+void pack_slices(std::vector<std::pair<uint32_t, std::vector<uint32_t>>> &tasks,  // (target, flat products)
+                 std::vector<SpiceySlice> &slices, std::vector<uint32_t> &tgt, std::vector<uint32_t> &cnt,
+                 std::vector<uint32_t> &pairs, std::vector<uint32_t> *aux_in = nullptr, std::vector<uint32_t> *aux_out = nullptr) {
+  std::vector<int> idx(tasks.size());
+  std::iota(idx.begin(), idx.end(), 0);
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return tasks[a].second.size() > tasks[b].second.size(); });
+  for (size_t s0 = 0; s0 < idx.size(); s0 += 64) {
+    size_t s1 = std::min(idx.size(), s0 + 64);
+    uint32_t len = (uint32_t)(tasks[idx[s0]].second.size() / W);
+    SpiceySlice sl;
+    sl.off = (uint32_t)pairs.size();
+    sl.len = len;
+    slices.push_back(sl);
+    pairs.resize(pairs.size() + (size_t)len * W * 64, 0u);
+    for (size_t l = 0; l < 64; l++) {
+      if (s0 + l < s1) {
+        auto &t = tasks[idx[s0 + l]];
+        tgt.push_back(t.first);
+        uint32_t c = (uint32_t)(t.second.size() / W);
+        cnt.push_back(c);
+        if (aux_in) aux_out->push_back((*aux_in)[idx[s0 + l]]);
+        for (uint32_t j = 0; j < c; j++)
+          for (int w = 0; w < W; w++) pairs[sl.off + ((size_t)j * W + w) * 64 + l] = t.second[(size_t)j * W + w];
+      } else {
+        tgt.push_back(SPICEY_TGT_PAD);
+        cnt.push_back(0);
+        if (aux_in) aux_out->push_back(0);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int64_t spicey_algorithmic_bytes(const SpiceyDesc *d, int32_t nnzA, int32_t nnzLU) {
+  // B = 8(3 nnzA + 2 nnzLU) + 4(nnzA + nnzLU) + 8*4*Nvar + 16(E_C+E_L+E_D) + 8(nNodes + E_total)
+  int64_t nvar = (int64_t)d->n_nodes + d->nV;
+  int64_t etot = (int64_t)d->nR + d->nC + d->nL + d->nV + d->nS + d->nD;
+  return 8 * (3 * (int64_t)nnzA + 2 * (int64_t)nnzLU) + 4 * ((int64_t)nnzA + nnzLU) + 32 * nvar +
+         16 * ((int64_t)d->nC + d->nL + d->nD) + 8 * ((int64_t)d->n_nodes + etot);
+}
+
+int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err) {
+  if (!d) { err = "null descriptor"; return SPICEY_ERR_BAD_DESC; }
+  if (d->abi_version != SPICEY_ABI_VERSION) { err = "abi_version mismatch"; return SPICEY_ERR_BAD_DESC; }
+  const int nN = d->n_nodes, nR = d->nR, nC = d->nC, nL = d->nL, nV = d->nV, nS = d->nS, nD = d->nD;
+  if (nN < 0 || nR < 0 || nC < 0 || nL < 0 || nV < 0 || nS < 0 || nD < 0 || d->n_inst < 1) {
+    err = "negative count or n_inst < 1";
+    return SPICEY_ERR_BAD_DESC;
+  }
+  const int n = nN + nV;
+  if (n == 0) { err = "empty circuit"; return SPICEY_ERR_BAD_DESC; }
+  auto chk = [&](const int32_t *a, const int32_t *b, int cnt, const char *what) -> bool {
+    if (cnt > 0 && (!a || !b)) { err = std::string("null node array for ") + what; return false; }
+    for (int i = 0; i < cnt; i++)
+      if (a[i] < 0 || a[i] > nN || b[i] < 0 || b[i] > nN) { err = std::string("node id out of range in ") + what; return false; }
+    return true;
+  };
+  if (!chk(d->R_n1, d->R_n2, nR, "R") || !chk(d->C_n1, d->C_n2, nC, "C") || !chk(d->L_n1, d->L_n2, nL, "L") ||
+      !chk(d->V_n1, d->V_n2, nV, "V") || !chk(d->S_n1, d->S_n2, nS, "S") || !chk(d->S_cp, d->S_cn, nS, "S control") ||
+      !chk(d->D_np, d->D_nm, nD, "D"))
+    return SPICEY_ERR_BAD_DESC;
+  if ((nR && !d->R_val) || (nC && !d->C_val) || (nL && !d->L_val) || (nS && (!d->S_ron || !d->S_roff || !d->S_von || !d->S_voff)) ||
+      (nD && (!d->D_is || !d->D_n))) {
+    err = "null value array";
+    return SPICEY_ERR_BAD_DESC;
+  }
+  const int nOut = (d->n_out > 0 && d->out_nodes) ? d->n_out : nN;
+  if (d->n_out > 0 && d->out_nodes)
+    for (int i = 0; i < nOut; i++)
+      if (d->out_nodes[i] < 0 || d->out_nodes[i] > nN) { err = "out_nodes id out of range"; return SPICEY_ERR_BAD_DESC; }
+
+  // ---- 1. pattern of A, by rows and by columns (original numbering) ---------------------------
+  Adj arow(n), acol(n);
+  auto add = [&](int r, int c) {
+    if (r < 0 || c < 0) return;
+    arow[r].push_back(c);
+    acol[c].push_back(r);
+  };
+  auto two_terminal = [&](const int32_t *a, const int32_t *b, int cnt) {
+    for (int i = 0; i < cnt; i++) {
+      int i1 = a[i] - 1, i2 = b[i] - 1;
+      add(i1, i1); add(i2, i2);
+      if (i1 >= 0 && i2 >= 0) { add(i1, i2); add(i2, i1); }
+    }
+  };
+  two_terminal(d->R_n1, d->R_n2, nR);
+  two_terminal(d->C_n1, d->C_n2, nC);
+  two_terminal(d->L_n1, d->L_n2, nL);
+  two_terminal(d->S_n1, d->S_n2, nS);
+  two_terminal(d->D_np, d->D_nm, nD);
+  // rows of each column with the voltage-source incidence rows FIRST (numerically +-1: preferred pivots)
+  Adj vrows(n);
+  for (int k = 0; k < nV; k++) {
+    int i1 = d->V_n1[k] - 1, i2 = d->V_n2[k] - 1, j = nN + k;
+    if (i1 == i2) continue;  // +1-1 cancels numerically; leave the branch row empty -> singular
+    add(i1, j); add(i2, j); add(j, i1); add(j, i2);
+    if (i1 >= 0) { vrows[i1].push_back(j); vrows[j].push_back(i1); }
+    if (i2 >= 0) { vrows[i2].push_back(j); vrows[j].push_back(i2); }
+  }
+  hp.nnzA = 0;
+  for (int r = 0; r < n; r++) { sort_unique(arow[r]); hp.nnzA += (int)arow[r].size(); }
+  Adj cand(n);
+  for (int c = 0; c < n; c++) {
+    sort_unique(acol[c]);
+    std::vector<int> pref = vrows[c];
+    sort_unique(pref);
+    cand[c] = pref;
+    for (int r : acol[c])
+      if (!std::binary_search(pref.begin(), pref.end(), r)) cand[c].push_back(r);
+  }
+
+  hp.hdr = SpiceyProg{};
+  hp.hdr.n = n; hp.hdr.nR = nR; hp.hdr.nC = nC; hp.hdr.nL = nL; hp.hdr.nV = nV; hp.hdr.nS = nS; hp.hdr.nD = nD;
+  hp.hdr.nU = nC + nL + nV + nD; hp.hdr.nGdyn = nS + nD; hp.hdr.nGstat = nR + nC + nL + 1;
+  hp.hdr.nOut = nOut; hp.hdr.nCur = nR + nC + nL + nV + nS + nD;
+
+  // ---- 2. zero-free diagonal ------------------------------------------------------------------
+  std::vector<int> row_of_col;
+  if (!max_transversal(n, cand, row_of_col)) {
+    hp.structurally_singular = true;
+    // keep a trivially valid (identity) program so that the handle can exist; run() reports singular
+    row_of_col.resize(n);
+    std::iota(row_of_col.begin(), row_of_col.end(), 0);
+    for (int c = 0; c < n; c++) { arow[c].push_back(c); sort_unique(arow[c]); }
+  }
+  std::vector<int> col_of_row(n);
+  for (int c = 0; c < n; c++) col_of_row[row_of_col[c]] = c;
+
+  // ---- 3. ordering on the symmetrised pattern of B = P A (B[c][*] = A[row_of_col[c]][*]) -------
+  Adj g(n);
+  for (int c = 0; c < n; c++)
+    for (int c2 : arow[row_of_col[c]])
+      if (c2 != c) { g[c].push_back(c2); g[c2].push_back(c); }
+  for (int c = 0; c < n; c++) sort_unique(g[c]);
+  NDOrder nd(g);
+  nd.run();
+  if ((int)nd.order.size() != n) { err = "internal: ordering lost vertices"; return SPICEY_ERR_BAD_DESC; }
+  hp.cpos.assign(n, -1);
+  for (int p = 0; p < n; p++) hp.cpos[nd.order[p]] = p;
+  hp.rpos.assign(n, -1);
+  for (int r = 0; r < n; r++) hp.rpos[r] = hp.cpos[col_of_row[r]];
+
+  // ---- 4. symbolic factorisation (symmetric pattern), etree, levels ----------------------------
+  Adj upper(n);  // struct of row k right of the diagonal = struct of column k below it
+  for (int c = 0; c < n; c++)
+    for (int c2 : g[c]) {
+      int a = hp.cpos[c], b = hp.cpos[c2];
+      if (b > a) upper[a].push_back(b);
+    }
+  hp.parent.assign(n, -1);
+  Adj children(n);
+  for (int k = 0; k < n; k++) {
+    std::vector<int> &S = upper[k];
+    for (int c : children[k])
+      for (int j : upper[c])
+        if (j != k) S.push_back(j);
+    sort_unique(S);
+    if (!S.empty()) {
+      hp.parent[k] = S[0];
+      children[S[0]].push_back(k);
+    }
+  }
+  hp.level.assign(n, 0);
+  int nLevels = 1;
+  for (int k = 0; k < n; k++) {
+    int l = 0;
+    for (int c : children[k]) l = std::max(l, hp.level[c] + 1);
+    hp.level[k] = l;
+    nLevels = std::max(nLevels, l + 1);
+  }
+  // CSR of L+U rows
+  EntryIndex E;
+  {
+    Adj rows(n);
+    for (int k = 0; k < n; k++) {
+      rows[k].push_back(k);
+      for (int j : upper[k]) { rows[k].push_back(j); rows[j].push_back(k); }
+    }
+    E.ptr.assign(n + 1, 0);
+    for (int r = 0; r < n; r++) {
+      sort_unique(rows[r]);
+      E.ptr[r + 1] = E.ptr[r] + (int)rows[r].size();
+    }
+    E.col.reserve(E.ptr[n]);
+    for (int r = 0; r < n; r++) E.col.insert(E.col.end(), rows[r].begin(), rows[r].end());
+  }
+  const int nLU = E.ptr[n];
+  hp.hdr.nLU = nLU; hp.hdr.nW = nLU + n; hp.hdr.nLevels = nLevels;
+  std::vector<int> diag(n);
+  for (int k = 0; k < n; k++) diag[k] = E.find(k, k);
+
+  // ---- 5a. stamp lists --------------------------------------------------------------------------
+  auto ent = [&](int r_orig, int c_orig) { return E.find(hp.rpos[r_orig], hp.cpos[c_orig]); };
+  std::vector<std::vector<uint32_t>> stat(nLU), dyn(nLU);
+  bool lookup_failed = false;
+  auto stamp2 = [&](std::vector<std::vector<uint32_t>> &dst, int n1, int n2, uint32_t gi) {
+    int i1 = n1 - 1, i2 = n2 - 1;
+    auto put = [&](int r, int c, uint32_t v) {
+      int e = ent(r, c);
+      if (e < 0) { lookup_failed = true; return; }
+      dst[e].push_back(v);
+    };
+    if (i1 >= 0) put(i1, i1, gi);
+    if (i2 >= 0) put(i2, i2, gi);
+    if (i1 >= 0 && i2 >= 0) { put(i1, i2, gi | SPICEY_NEG); put(i2, i1, gi | SPICEY_NEG); }
+  };
+  for (int i = 0; i < nR; i++) stamp2(stat, d->R_n1[i], d->R_n2[i], (uint32_t)i);
+  for (int i = 0; i < nC; i++) stamp2(stat, d->C_n1[i], d->C_n2[i], (uint32_t)(nR + i));
+  for (int i = 0; i < nL; i++) stamp2(stat, d->L_n1[i], d->L_n2[i], (uint32_t)(nR + nC + i));
+  for (int i = 0; i < nS; i++) stamp2(dyn, d->S_n1[i], d->S_n2[i], (uint32_t)i);
+  if (!hp.structurally_singular) {
+    const uint32_t one = (uint32_t)(nR + nC + nL);
+    for (int k = 0; k < nV; k++) {  // stampVoltageSourceReal.ts:12-31
+      int i1 = d->V_n1[k] - 1, i2 = d->V_n2[k] - 1, j = nN + k;
+      if (i1 == i2) continue;
+      auto put = [&](int r, int c, uint32_t v) {
+        int e = ent(r, c);
+        if (e < 0) { lookup_failed = true; return; }
+        stat[e].push_back(v);
+      };
+      if (i1 >= 0) put(i1, j, one);
+      if (i2 >= 0) put(i2, j, one | SPICEY_NEG);
+      if (i1 >= 0) put(j, i1, one);
+      if (i2 >= 0) put(j, i2, one | SPICEY_NEG);
+    }
+  }
+  for (int i = 0; i < nD; i++) stamp2(dyn, d->D_np[i], d->D_nm[i], (uint32_t)(nS + i));
+  if (lookup_failed) { err = "internal: stamp outside the symbolic pattern"; return SPICEY_ERR_BAD_DESC; }
+
+  hp.ent_flag.assign(nLU, 0);
+  for (int k = 0; k < n; k++)
+    if (hp.level[k] == 0) hp.ent_flag[diag[k]] |= 1;
+  hp.stat_ptr.assign(1, 0);
+  hp.stat_idx.clear();
+  hp.dyn_ent.clear(); hp.dyn_ptr.assign(1, 0); hp.dyn_idx.clear();
+  for (int e = 0; e < nLU; e++) {
+    hp.stat_idx.insert(hp.stat_idx.end(), stat[e].begin(), stat[e].end());
+    hp.stat_ptr.push_back((uint32_t)hp.stat_idx.size());
+    if (!dyn[e].empty()) {
+      hp.ent_flag[e] |= 2;
+      hp.dyn_ent.push_back((uint32_t)e | ((hp.ent_flag[e] & 1) ? SPICEY_TGT_RECIP : 0u));
+      hp.dyn_idx.insert(hp.dyn_idx.end(), dyn[e].begin(), dyn[e].end());
+      hp.dyn_ptr.push_back((uint32_t)hp.dyn_idx.size());
+    }
+  }
+  hp.hdr.nDynEnt = (int32_t)hp.dyn_ent.size();
+
+  // right-hand side (stampCurrentReal.ts:3-14: b[i+] -= I, b[i-] += I; order C, L, V, D)
+  {
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> rows(n);  // (u idx|sign, gstat coef idx)
+    const uint32_t one = (uint32_t)(nR + nC + nL);
+    auto cur = [&](int np, int nm, uint32_t ui, uint32_t cof, bool negate_value) {
+      // contributes  -I to row np-1 and +I to row nm-1, where I = (negate_value ? -1 : 1) * cof * u[ui]
+      int ip = np - 1, im = nm - 1;
+      if (ip >= 0) rows[hp.rpos[ip]].emplace_back(ui | (negate_value ? 0u : SPICEY_NEG), cof);
+      if (im >= 0) rows[hp.rpos[im]].emplace_back(ui | (negate_value ? SPICEY_NEG : 0u), cof);
+    };
+    for (int i = 0; i < nC; i++) cur(d->C_n1[i], d->C_n2[i], (uint32_t)i, (uint32_t)(nR + i), true);  // Ieq = -Gc*vPrev
+    for (int i = 0; i < nL; i++) cur(d->L_n1[i], d->L_n2[i], (uint32_t)(nC + i), one, false);          // I = iPrev
+    for (int k = 0; k < nV; k++) rows[hp.rpos[nN + k]].emplace_back((uint32_t)(nC + nL + k), one);     // b[j] += V
+    for (int i = 0; i < nD; i++) cur(d->D_np[i], d->D_nm[i], (uint32_t)(nC + nL + nV + i), one, false);  // I = ieq
+    hp.rhs_ptr.assign(1, 0);
+    hp.rhs_idx.clear(); hp.rhs_cof.clear();
+    for (int r = 0; r < n; r++) {
+      for (auto &p : rows[r]) { hp.rhs_idx.push_back(p.first); hp.rhs_cof.push_back(p.second); }
+      hp.rhs_ptr.push_back((uint32_t)hp.rhs_idx.size());
+    }
+    hp.hdr.nRhsIdx = (int32_t)hp.rhs_idx.size();
+  }
+
+  // ---- 5b. factorisation tasks per level ---------------------------------------------------------
+  hp.lvl_slice.assign(1, 0);
+  hp.upd_slice.clear(); hp.upd_tgt.clear(); hp.upd_cnt.clear(); hp.upd_pairs.clear();
+  hp.n_products = 0;
+  std::vector<std::vector<int>> by_level(nLevels);
+  for (int k = 0; k < n; k++) by_level[hp.level[k]].push_back(k);
+  for (int l = 0; l < nLevels; l++) {
+    // (target, pivot, L entry, U entry) tuples, grouped by target in pivot order
+    struct Prod { uint32_t tgt, l, d, u; };
+    std::vector<Prod> prods;
+    for (int k : by_level[l]) {
+      const std::vector<int> &S = upper[k];
+      for (int a : S) {
+        uint32_t le = (uint32_t)E.find(a, k);
+        for (int b : S) prods.push_back({(uint32_t)E.find(a, b), le, (uint32_t)diag[k], (uint32_t)E.find(k, b)});
+        prods.push_back({(uint32_t)(nLU + a), le, (uint32_t)diag[k], (uint32_t)(nLU + k)});  // fused forward elimination
+      }
+    }
+    std::stable_sort(prods.begin(), prods.end(), [](const Prod &x, const Prod &y) { return x.tgt < y.tgt; });
+    std::vector<std::pair<uint32_t, std::vector<uint32_t>>> tasks;
+    for (size_t i = 0; i < prods.size();) {
+      size_t j = i;
+      std::vector<uint32_t> flat;
+      while (j < prods.size() && prods[j].tgt == prods[i].tgt) {
+        flat.push_back(prods[j].l); flat.push_back(prods[j].d); flat.push_back(prods[j].u);
+        j++;
+      }
+      uint32_t t = prods[i].tgt;
+      if ((int)t < nLU) {
+        // diagonal that becomes final now?
+        int r = (int)(std::upper_bound(E.ptr.begin(), E.ptr.end(), (int)t) - E.ptr.begin()) - 1;
+        if (E.col[t] == r && hp.level[r] == l + 1) t |= SPICEY_TGT_RECIP;
+      }
+      tasks.emplace_back(t, std::move(flat));
+      i = j;
+    }
+    hp.n_products += (int64_t)prods.size();
+    pack_slices<3>(tasks, hp.upd_slice, hp.upd_tgt, hp.upd_cnt, hp.upd_pairs);
+    hp.lvl_slice.push_back((uint32_t)hp.upd_slice.size());
+  }
+  hp.hdr.nUpdSlices = (int32_t)hp.upd_slice.size();
+
+  // ---- 5c. backward substitution tasks per level -------------------------------------------------
+  hp.bk_lvl_slice.assign(1, 0);
+  hp.bk_slice.clear(); hp.bk_x.clear(); hp.bk_d.clear(); hp.bk_cnt.clear(); hp.bk_pairs.clear();
+  hp.n_bk_products = 0;
+  for (int l = 0; l < nLevels; l++) {
+    std::vector<std::pair<uint32_t, std::vector<uint32_t>>> tasks;
+    std::vector<uint32_t> dd;
+    for (int k : by_level[l]) {
+      std::vector<uint32_t> flat;
+      for (int b : upper[k]) { flat.push_back((uint32_t)E.find(k, b)); flat.push_back((uint32_t)(nLU + b)); }
+      hp.n_bk_products += (int64_t)upper[k].size();
+      tasks.emplace_back((uint32_t)(nLU + k), std::move(flat));
+      dd.push_back((uint32_t)diag[k]);
+    }
+    pack_slices<2>(tasks, hp.bk_slice, hp.bk_x, hp.bk_cnt, hp.bk_pairs, &dd, &hp.bk_d);
+    hp.bk_lvl_slice.push_back((uint32_t)hp.bk_slice.size());
+  }
+  hp.hdr.nBkSlices = (int32_t)hp.bk_slice.size();
+
+  // ---- 5d. element terminals and outputs as W indices -------------------------------------------
+  auto xpos = [&](int node) -> int32_t { return node == 0 ? -1 : (int32_t)(nLU + hp.cpos[node - 1]); };
+  auto map2 = [&](const int32_t *a, const int32_t *b, int cnt, std::vector<int32_t> &oa, std::vector<int32_t> &ob) {
+    oa.resize(cnt); ob.resize(cnt);
+    for (int i = 0; i < cnt; i++) { oa[i] = xpos(a[i]); ob[i] = xpos(b[i]); }
+  };
+  map2(d->R_n1, d->R_n2, nR, hp.R_a, hp.R_b);
+  map2(d->C_n1, d->C_n2, nC, hp.C_a, hp.C_b);
+  map2(d->L_n1, d->L_n2, nL, hp.L_a, hp.L_b);
+  map2(d->S_n1, d->S_n2, nS, hp.S_a, hp.S_b);
+  map2(d->S_cp, d->S_cn, nS, hp.S_cp, hp.S_cn);
+  map2(d->D_np, d->D_nm, nD, hp.D_a, hp.D_b);
+  hp.V_x.resize(nV);
+  for (int k = 0; k < nV; k++) hp.V_x[k] = nLU + hp.cpos[nN + k];
+  hp.out_x.resize(nOut);
+  for (int i = 0; i < nOut; i++) hp.out_x[i] = (d->n_out > 0 && d->out_nodes) ? xpos(d->out_nodes[i]) : (int32_t)(nLU + hp.cpos[i]);
+
+  hp.pack();
+  return SPICEY_OK;
+}
+
+void HostProgram::pack() {
+  blob.clear();
+  offsets.clear();
+  add_section(blob, offsets, stat_ptr);   // 0
+  add_section(blob, offsets, stat_idx);   // 1
+  add_section(blob, offsets, ent_flag);   // 2
+  add_section(blob, offsets, dyn_ent);    // 3
+  add_section(blob, offsets, dyn_ptr);    // 4
+  add_section(blob, offsets, dyn_idx);    // 5
+  add_section(blob, offsets, rhs_ptr);    // 6
+  add_section(blob, offsets, rhs_idx);    // 7
+  add_section(blob, offsets, rhs_cof);    // 8
+  add_section(blob, offsets, lvl_slice);  // 9
+  add_section(blob, offsets, upd_slice);  // 10
+  add_section(blob, offsets, upd_tgt);    // 11
+  add_section(blob, offsets, upd_cnt);    // 12
+  add_section(blob, offsets, upd_pairs);  // 13
+  add_section(blob, offsets, bk_lvl_slice);  // 14
+  add_section(blob, offsets, bk_slice);   // 15
+  add_section(blob, offsets, bk_x);       // 16
+  add_section(blob, offsets, bk_d);       // 17
+  add_section(blob, offsets, bk_cnt);     // 18
+  add_section(blob, offsets, bk_pairs);   // 19
+  add_section(blob, offsets, R_a); add_section(blob, offsets, R_b);    // 20 21
+  add_section(blob, offsets, C_a); add_section(blob, offsets, C_b);    // 22 23
+  add_section(blob, offsets, L_a); add_section(blob, offsets, L_b);    // 24 25
+  add_section(blob, offsets, S_a); add_section(blob, offsets, S_b);    // 26 27
+  add_section(blob, offsets, S_cp); add_section(blob, offsets, S_cn);  // 28 29
+  add_section(blob, offsets, D_a); add_section(blob, offsets, D_b);    // 30 31
+  add_section(blob, offsets, V_x);    // 32
+  add_section(blob, offsets, out_x);  // 33
+}
+
+SpiceyProg HostProgram::bind(const void *base) const {
+  SpiceyProg p = hdr;
+  const uint8_t *b = (const uint8_t *)base;
+  auto u32 = [&](int i) { return (const uint32_t *)(b + offsets[i]); };
+  auto i32 = [&](int i) { return (const int32_t *)(b + offsets[i]); };
+  p.stat_ptr = u32(0); p.stat_idx = u32(1); p.ent_flag = (const uint8_t *)(b + offsets[2]);
+  p.dyn_ent = u32(3); p.dyn_ptr = u32(4); p.dyn_idx = u32(5);
+  p.rhs_ptr = u32(6); p.rhs_idx = u32(7); p.rhs_cof = u32(8);
+  p.lvl_slice = u32(9); p.upd_slice = (const SpiceySlice *)(b + offsets[10]);
+  p.upd_tgt = u32(11); p.upd_cnt = u32(12); p.upd_pairs = u32(13);
+  p.bk_lvl_slice = u32(14); p.bk_slice = (const SpiceySlice *)(b + offsets[15]);
+  p.bk_x = u32(16); p.bk_d = u32(17); p.bk_cnt = u32(18); p.bk_pairs = u32(19);
+  p.R_a = i32(20); p.R_b = i32(21); p.C_a = i32(22); p.C_b = i32(23); p.L_a = i32(24); p.L_b = i32(25);
+  p.S_a = i32(26); p.S_b = i32(27); p.S_cp = i32(28); p.S_cn = i32(29); p.D_a = i32(30); p.D_b = i32(31);
+  p.V_x = i32(32); p.out_x = i32(33);
+  return p;
+}

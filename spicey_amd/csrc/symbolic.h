@@ -1,0 +1,46 @@
+// symbolic.h — host symbolic phase: topology -> device program (see symbolic.cpp).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/spicey_hip.h"
+#include "program.h"
+
+struct HostProgram {
+  SpiceyProg hdr{};  // counts filled; pointers filled by bind()
+  bool structurally_singular = false;
+  int32_t nnzA = 0;
+  int64_t n_products = 0;  // multiply-adds of one factorisation (incl. fused forward elimination)
+  int64_t n_bk_products = 0;
+
+  std::vector<int32_t> cpos, rpos;  // original column / row -> pivot position
+  std::vector<int32_t> level;       // per pivot position
+  std::vector<int32_t> parent;      // etree
+
+  std::vector<uint32_t> stat_ptr, stat_idx;
+  std::vector<uint8_t> ent_flag;
+  std::vector<uint32_t> dyn_ent, dyn_ptr, dyn_idx;
+  std::vector<uint32_t> rhs_ptr, rhs_idx, rhs_cof;
+  std::vector<uint32_t> lvl_slice, upd_tgt, upd_cnt, upd_pairs;
+  std::vector<SpiceySlice> upd_slice;
+  std::vector<uint32_t> bk_lvl_slice, bk_x, bk_d, bk_cnt, bk_pairs;
+  std::vector<SpiceySlice> bk_slice;
+  std::vector<int32_t> R_a, R_b, C_a, C_b, L_a, L_b, S_a, S_b, S_cp, S_cn, D_a, D_b, V_x, out_x;
+
+  // Serialise all arrays into one blob (16-byte aligned sections) and return a SpiceyProg whose
+  // pointers are `base + offset`.  `base` may be a device address: the blob is then memcpy'd there.
+  std::vector<uint8_t> blob;
+  void pack();
+  SpiceyProg bind(const void *base) const;
+  std::vector<size_t> offsets;  // section offsets in pack() order
+};
+
+// Builds the program for `d`'s topology.  Returns SPICEY_OK or SPICEY_ERR_BAD_DESC (err filled).
+// A structurally singular matrix is not an error here: hp.structurally_singular is set and the
+// run reports SPICEY_ERR_SINGULAR, like the reference throws at the first solve.
+int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err);
+
+// SURVEY.md §8(d) algorithmic bytes per solve.
+int64_t spicey_algorithmic_bytes(const SpiceyDesc *d, int32_t nnzA, int32_t nnzLU);

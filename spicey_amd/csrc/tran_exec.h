@@ -1,0 +1,373 @@
+// tran_exec.h — the per-workgroup transient program interpreter (device code, host-compilable).
+//
+// One workgroup owns K instances (same topology, interleaved [index][K] in LDS) and runs the whole
+// `for step … for iter …` nest of /root/reference/lib/analysis/simulateTRAN.ts:146-238 for them
+// inside ONE kernel launch.  Every function below is the body of one barrier-separated PHASE;
+// inside a phase the threads are independent (gather form: each thread owns what it writes, reads
+// only data finalised in earlier phases), so the same code can be
+//   * the HIP kernel (kernels.hip): `phase(f)` = f(threadIdx.x); __syncthreads();
+//   * the CPU test emulator (tests/emul): `phase(f)` = for tid in 0..T-1: f(tid)
+// The emulator is test infrastructure for the symbolic phase and this interpreter; the product
+// path only ever runs the HIP kernel.
+//
+// Phases per time step (nLev = elimination-tree height):
+//   B    dynamic stamps (switch / diode conductances) + right-hand side          simulateTRAN.ts:25-102
+//   U_l  l = 0..nLev-2: Schur updates of level l with the forward elimination fused in as an extra
+//        column; diagonals that become final are stored as reciprocals (singularity check = solveReal.ts:28)
+//   K_l  l = nLev-1..0: backward substitution                                    solveReal.ts:56-72
+//   S    switch hysteresis + iteration control (only if the circuit has switches) simulateTRAN.ts:108-128,151-162
+//   Z    recording, state update, and the NEXT step's element evaluation          simulateTRAN.ts:164-237
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "program.h"
+
+#if defined(__HIPCC__)
+#define SPICEY_HD __host__ __device__ __forceinline__
+#else
+#define SPICEY_HD inline
+#endif
+
+template <int K>
+struct WgCtx {
+  double *W;     // [nW][K]   L+U entries, then rhs / x'
+  double *u;     // [nU][K]   vPrev | iPrev | V(t) | diode ieq
+  double *gd;    // [nGdyn][K] switch conductances | diode gd
+  int32_t *ison; // [nS][K]
+  int32_t *flags;  // [0] switched, [1] singular code, [2] singular inst
+  int32_t inst[K];
+  int32_t valid[K];
+};
+
+SPICEY_HD double spicey_max_nan(double a, double b) {  // Math.max semantics
+  return (a > b || a != a) ? a : b;
+}
+
+// Diode companion model, simulateTRAN.ts:87-98.  `e_in` >= 0: exp(vd/vt) already known and vd unclamped.
+SPICEY_HD void spicey_diode(double vd, double is, double nn, double &gd, double &ieq) {
+  const double vt = nn * SPICEY_VT300;
+  double vl = vd;
+  if (vd > 0.8) vl = 0.8;
+  if (vd < -1.0) vl = -1.0;
+  const double e = exp(vl / vt);
+  const double id = is * (e - 1.0);
+  gd = spicey_max_nan((is / vt) * e, 1e-12);
+  ieq = id - gd * vl;
+}
+
+SPICEY_HD double spicey_switch_g(int on, double ron, double roff) {  // simulateTRAN.ts:59-61
+  const double r = on ? ron : roff;
+  return 1.0 / spicey_max_nan(fabs(r), SPICEY_EPS);
+}
+
+template <int K>
+struct TranPhases {
+  const SpiceyProg &P;
+  const SpiceyRun &R;
+  WgCtx<K> &c;
+  int T;  // threads
+
+  SPICEY_HD double volt(int32_t xi, int k) const { return xi < 0 ? 0.0 : c.W[(size_t)xi * K + k]; }
+
+  // ---- prologue -----------------------------------------------------------------------------
+  SPICEY_HD void p0_gstat(int tid) const {
+    const double dtc = spicey_max_nan(R.dt, SPICEY_EPS);
+    for (int k = 0; k < K; k++) {
+      if (!c.valid[k]) continue;
+      const size_t in = (size_t)c.inst[k];
+      double *g = R.gstat + in * P.nGstat;
+      for (int i = tid; i < P.nGstat; i += T) {
+        double v;
+        if (i < P.nR) v = 1.0 / R.R_val[in * P.nR + i];
+        else if (i < P.nR + P.nC) v = R.C_val[in * P.nC + (i - P.nR)] / dtc;
+        else if (i < P.nR + P.nC + P.nL) v = dtc / R.L_val[in * P.nL + (i - P.nR - P.nC)];
+        else v = 1.0;
+        g[i] = v;
+      }
+    }
+  }
+  SPICEY_HD void p1_static(int tid) const {
+    for (int k = 0; k < K; k++) {
+      if (!c.valid[k]) continue;
+      const size_t in = (size_t)c.inst[k];
+      const double *g = R.gstat + in * P.nGstat;
+      double *sv = R.statv + in * P.nLU;
+      for (int e = tid; e < P.nLU; e += T) {
+        double v = 0.0;
+        for (uint32_t j = P.stat_ptr[e]; j < P.stat_ptr[e + 1]; j++) {
+          const uint32_t ix = P.stat_idx[j];
+          const double gv = g[SPICEY_IDX(ix)];
+          v = (ix & SPICEY_NEG) ? v - gv : v + gv;
+        }
+        if (P.ent_flag[e] == 1) {  // static leaf diagonal: pre-invert once per run
+          if (fabs(v) < SPICEY_EPS) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
+          v = 1.0 / v;
+        }
+        sv[e] = v;
+      }
+      double *rc = R.rcoef + in * P.nRhsIdx;
+      for (int j = tid; j < P.nRhsIdx; j += T) rc[j] = g[P.rhs_cof[j]];
+    }
+  }
+  // evaluate elements from the state entering the run (step 0, iter 0)
+  SPICEY_HD void a0_initial(int tid) const {
+    const int oL = P.nC, oV = P.nC + P.nL, oD = P.nC + P.nL + P.nV;
+    for (int k = 0; k < K; k++) {
+      const size_t in = (size_t)c.inst[k];
+      for (int i = tid; i < P.nC; i += T) c.u[(size_t)i * K + k] = R.C_vprev[in * P.nC + i];
+      for (int i = tid; i < P.nL; i += T) c.u[(size_t)(oL + i) * K + k] = R.L_iprev[in * P.nL + i];
+      for (int i = tid; i < P.nV; i += T) c.u[(size_t)(oV + i) * K + k] = R.src[i];
+      for (int i = tid; i < P.nS; i += T) {
+        const int on = R.S_ison[in * P.nS + i];
+        c.ison[(size_t)i * K + k] = on;
+        c.gd[(size_t)i * K + k] = spicey_switch_g(on, R.S_ron[in * P.nS + i], R.S_roff[in * P.nS + i]);
+      }
+      for (int i = tid; i < P.nD; i += T) {
+        double g, q;
+        spicey_diode(R.D_vdprev[in * P.nD + i], R.D_is[in * P.nD + i], R.D_n[in * P.nD + i], g, q);
+        c.gd[(size_t)(P.nS + i) * K + k] = g;
+        c.u[(size_t)(oD + i) * K + k] = q;
+      }
+    }
+    static_copy(tid);
+    if (tid == 0) c.flags[0] = 0;
+  }
+  SPICEY_HD void static_copy(int tid) const {
+    for (int k = 0; k < K; k++) {
+      const double *sv = R.statv + (size_t)c.inst[k] * P.nLU;
+      for (int e = tid; e < P.nLU; e += T) c.W[(size_t)e * K + k] = sv[e];
+    }
+  }
+
+  // ---- B: dynamic stamps + right-hand side ----------------------------------------------------
+  SPICEY_HD void b_stamp(int tid) const {
+    if (tid == 0) c.flags[0] = 0;
+    for (int t = tid; t < P.nDynEnt; t += T) {
+      const uint32_t et = P.dyn_ent[t];
+      const uint32_t e = SPICEY_IDX(et);
+      const uint32_t j0 = P.dyn_ptr[t], j1 = P.dyn_ptr[t + 1];
+      for (int k = 0; k < K; k++) {
+        double v = R.statv[(size_t)c.inst[k] * P.nLU + e];
+        for (uint32_t j = j0; j < j1; j++) {
+          const uint32_t ix = P.dyn_idx[j];
+          const double gv = c.gd[(size_t)SPICEY_IDX(ix) * K + k];
+          v = (ix & SPICEY_NEG) ? v - gv : v + gv;
+        }
+        if (et & SPICEY_TGT_RECIP) {
+          if (fabs(v) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
+          v = 1.0 / v;
+        }
+        c.W[(size_t)e * K + k] = v;
+      }
+    }
+    for (int r = tid; r < P.n; r += T) {
+      const uint32_t j0 = P.rhs_ptr[r], j1 = P.rhs_ptr[r + 1];
+      for (int k = 0; k < K; k++) {
+        const double *rc = R.rcoef + (size_t)c.inst[k] * P.nRhsIdx;
+        double acc = 0.0;
+        for (uint32_t j = j0; j < j1; j++) {
+          const uint32_t ix = P.rhs_idx[j];
+          const double t = rc[j] * c.u[(size_t)SPICEY_IDX(ix) * K + k];
+          acc = (ix & SPICEY_NEG) ? acc - t : acc + t;
+        }
+        c.W[(size_t)(P.nLU + r) * K + k] = acc;
+      }
+    }
+  }
+
+  // ---- U_l: Schur updates of one elimination-tree level ----------------------------------------
+  SPICEY_HD void u_level(int tid, int l) const {
+    const int nw = T >> 6, w = tid >> 6, lane = tid & 63;
+    for (uint32_t s = P.lvl_slice[l] + w; s < P.lvl_slice[l + 1]; s += nw) {
+      const uint32_t t = s * 64 + lane;
+      const uint32_t tgt = P.upd_tgt[t];
+      if (tgt == SPICEY_TGT_PAD) continue;
+      const uint32_t cnt = P.upd_cnt[t];
+      const uint32_t off = P.upd_slice[s].off + lane;
+      const uint32_t ti = SPICEY_IDX(tgt);
+      double acc[K];
+      for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)ti * K + k];
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t li = P.upd_pairs[off + (j * 3 + 0) * 64];
+        const uint32_t di = P.upd_pairs[off + (j * 3 + 1) * 64];
+        const uint32_t ui = P.upd_pairs[off + (j * 3 + 2) * 64];
+        for (int k = 0; k < K; k++)
+          acc[k] -= (c.W[(size_t)li * K + k] * c.W[(size_t)di * K + k]) * c.W[(size_t)ui * K + k];
+      }
+      if (tgt & SPICEY_TGT_RECIP) {
+        for (int k = 0; k < K; k++) {
+          if (fabs(acc[k]) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
+          acc[k] = 1.0 / acc[k];
+        }
+      }
+      for (int k = 0; k < K; k++) c.W[(size_t)ti * K + k] = acc[k];
+    }
+  }
+
+  // ---- K_l: backward substitution of one level --------------------------------------------------
+  SPICEY_HD void k_level(int tid, int l) const {
+    const int nw = T >> 6, w = tid >> 6, lane = tid & 63;
+    for (uint32_t s = P.bk_lvl_slice[l] + w; s < P.bk_lvl_slice[l + 1]; s += nw) {
+      const uint32_t t = s * 64 + lane;
+      const uint32_t xi = P.bk_x[t];
+      if (xi == SPICEY_TGT_PAD) continue;
+      const uint32_t cnt = P.bk_cnt[t], di = P.bk_d[t];
+      const uint32_t off = P.bk_slice[s].off + lane;
+      double acc[K];
+      for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)xi * K + k];
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t ui = P.bk_pairs[off + (j * 2 + 0) * 64];
+        const uint32_t xb = P.bk_pairs[off + (j * 2 + 1) * 64];
+        for (int k = 0; k < K; k++) acc[k] -= c.W[(size_t)ui * K + k] * c.W[(size_t)xb * K + k];
+      }
+      for (int k = 0; k < K; k++) c.W[(size_t)xi * K + k] = acc[k] * c.W[(size_t)di * K + k];
+    }
+  }
+
+  // ---- S: switch hysteresis (updateSwitchStatesFromSolution, simulateTRAN.ts:108-128) -----------
+  SPICEY_HD void s_switches(int tid) const {
+    for (int i = tid; i < P.nS; i += T)
+      for (int k = 0; k < K; k++) {
+        const size_t in = (size_t)c.inst[k];
+        const double vctrl = volt(P.S_cp[i], k) - volt(P.S_cn[i], k);
+        const int on = c.ison[(size_t)i * K + k];
+        int next = on;
+        if (on) {
+          if (vctrl < R.S_voff[in * P.nS + i]) next = 0;
+        } else if (vctrl > R.S_von[in * P.nS + i]) {
+          next = 1;
+        }
+        if (next != on) {
+          c.ison[(size_t)i * K + k] = next;
+          c.flags[0] = 1;
+        }
+      }
+  }
+  // ---- A': re-linearise for iteration >= 1 (diodes from x, simulateTRAN.ts:81-85) ----------------
+  SPICEY_HD void a_reiterate(int tid) const {
+    const int oD = P.nC + P.nL + P.nV;
+    for (int k = 0; k < K; k++) {
+      const size_t in = (size_t)c.inst[k];
+      for (int i = tid; i < P.nS; i += T)
+        c.gd[(size_t)i * K + k] = spicey_switch_g(c.ison[(size_t)i * K + k], R.S_ron[in * P.nS + i], R.S_roff[in * P.nS + i]);
+      for (int i = tid; i < P.nD; i += T) {
+        double g, q;
+        spicey_diode(volt(P.D_a[i], k) - volt(P.D_b[i], k), R.D_is[in * P.nD + i], R.D_n[in * P.nD + i], g, q);
+        c.gd[(size_t)(P.nS + i) * K + k] = g;
+        c.u[(size_t)(oD + i) * K + k] = q;
+      }
+    }
+    static_copy(tid);
+  }
+
+  // ---- Z: record, update state, evaluate the next step's companions ----------------------------
+  SPICEY_HD void z_record(int tid, int64_t step) const {
+    const bool last = step == R.steps;
+    const int oL = P.nC, oV = P.nC + P.nL, oD = P.nC + P.nL + P.nV;
+    const int cR = 0, cC = P.nR, cL = P.nR + P.nC, cV = cL + P.nL, cS = cV + P.nV, cD = cS + P.nS;
+    for (int k = 0; k < K; k++) {
+      if (!c.valid[k]) continue;
+      const size_t in = (size_t)c.inst[k];
+      double *ov = R.out_v + (in * (size_t)(R.steps + 1) + (size_t)step) * P.nOut;
+      for (int i = tid; i < P.nOut; i += T) ov[i] = volt(P.out_x[i], k);
+      const bool cur = R.out_i != nullptr;
+      double *oi = cur ? R.out_i + (in * (size_t)(R.steps + 1) + (size_t)step) * P.nCur : nullptr;
+      const double *g = R.gstat + in * P.nGstat;
+      if (cur)
+        for (int i = tid; i < P.nR; i += T) oi[cR + i] = (volt(P.R_a[i], k) - volt(P.R_b[i], k)) * g[i];
+      for (int i = tid; i < P.nC; i += T) {
+        const double dv = volt(P.C_a[i], k) - volt(P.C_b[i], k);
+        if (cur) oi[cC + i] = g[P.nR + i] * (dv - c.u[(size_t)i * K + k]);
+        c.u[(size_t)i * K + k] = dv;
+        if (last) R.C_vprev[in * P.nC + i] = dv;
+      }
+      for (int i = tid; i < P.nL; i += T) {
+        const double dv = volt(P.L_a[i], k) - volt(P.L_b[i], k);
+        const double il = g[P.nR + P.nC + i] * dv + c.u[(size_t)(oL + i) * K + k];
+        if (cur) oi[cL + i] = il;
+        c.u[(size_t)(oL + i) * K + k] = il;
+        if (last) R.L_iprev[in * P.nL + i] = il;
+      }
+      for (int i = tid; i < P.nV; i += T) {
+        if (cur) oi[cV + i] = c.W[(size_t)P.V_x[i] * K + k];
+        if (!last) c.u[(size_t)(oV + i) * K + k] = R.src[(size_t)(step + 1) * P.nV + i];
+      }
+      for (int i = tid; i < P.nS; i += T) {
+        const int on = c.ison[(size_t)i * K + k];
+        const double gs = spicey_switch_g(on, R.S_ron[in * P.nS + i], R.S_roff[in * P.nS + i]);
+        if (cur) oi[cS + i] = (volt(P.S_a[i], k) - volt(P.S_b[i], k)) * gs;
+        c.gd[(size_t)i * K + k] = gs;
+        if (last) R.S_ison[in * P.nS + i] = on;
+      }
+      for (int i = tid; i < P.nD; i += T) {
+        const double vd = volt(P.D_a[i], k) - volt(P.D_b[i], k);
+        const double is = R.D_is[in * P.nD + i], nn = R.D_n[in * P.nD + i];
+        if (cur) oi[cD + i] = is * (exp(vd / (nn * SPICEY_VT300)) - 1.0);  // unclamped, simulateTRAN.ts:214-217
+        double gg, q;
+        spicey_diode(vd, is, nn, gg, q);
+        c.gd[(size_t)(P.nS + i) * K + k] = gg;
+        c.u[(size_t)(oD + i) * K + k] = q;
+        if (last) R.D_vdprev[in * P.nD + i] = vd;
+      }
+    }
+    static_copy(tid);
+  }
+};
+
+// The whole run of one workgroup.  Exec supplies `phase(f)` (run f(tid) for every thread, then
+// barrier) and `threads()`.  All control flow is workgroup-uniform: flags are read after barriers.
+template <int K, class Exec>
+SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R, WgCtx<K> &c, int wg) {
+  TranPhases<K> ph{P, R, c, ex.threads()};
+  ex.phase([&](int tid) {
+    if (tid == 0) { c.flags[0] = 0; c.flags[1] = 0; c.flags[2] = -1; }
+    ph.p0_gstat(tid);
+  });
+  ex.phase([&](int tid) { ph.p1_static(tid); });
+  ex.phase([&](int tid) { ph.a0_initial(tid); });
+  unsigned long long solves = 0;
+  int32_t code = 0;
+  int64_t err_step = 0;
+  int32_t err_iter = 0;
+  if (c.flags[1]) { code = 1; }
+  for (int64_t step = 0; step <= R.steps && code == 0; step++) {
+    int iter = 0;
+    for (;;) {
+      ex.phase([&](int tid) { ph.b_stamp(tid); });
+      for (int l = 0; l < P.nLevels; l++) {
+        if (P.lvl_slice[l] == P.lvl_slice[l + 1]) continue;
+        ex.phase([&](int tid) { ph.u_level(tid, l); });
+      }
+      for (int l = P.nLevels - 1; l >= 0; l--) ex.phase([&](int tid) { ph.k_level(tid, l); });
+      if (c.flags[1]) { code = 1; err_step = step; err_iter = iter; break; }
+      if (P.nS == 0) break;
+      ex.phase([&](int tid) { ph.s_switches(tid); });
+      const int switched = c.flags[0];
+      if (!switched || iter == SPICEY_MAX_ITER - 1) break;
+      iter++;
+      ex.phase([&](int tid) { ph.a_reiterate(tid); });  // b_stamp (next) resets flags[0] after this barrier
+    }
+    if (code) break;
+    {
+      int nvalid = 0;
+      for (int k = 0; k < K; k++) nvalid += c.valid[k];
+      solves += (unsigned long long)(iter + 1) * (unsigned long long)nvalid;
+    }
+    ex.phase([&](int tid) {
+      if (tid == 0 && R.iters)
+        for (int k = 0; k < K; k++)
+          if (c.valid[k]) R.iters[(size_t)c.inst[k] * (size_t)(R.steps + 1) + (size_t)step] = iter + 1;
+      ph.z_record(tid, step);
+    });
+  }
+  ex.phase([&](int tid) {
+    if (tid == 0) {
+      R.status[wg * 4 + 0] = code;
+      R.status[wg * 4 + 1] = c.flags[2];
+      R.status[wg * 4 + 2] = (int32_t)err_step;
+      R.status[wg * 4 + 3] = err_iter;
+      R.solves[wg] = solves;
+    }
+  });
+}

@@ -1,0 +1,161 @@
+"""ctypes binding of libspicey_hip.so — the only compute path of this package.
+
+Loading fails loudly when the shared library is missing (run ``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C spicey_amd/csrc``); creating a handle fails with
+SPICEY_ERR_NO_DEVICE when there is no GPU.  Nothing here falls back to a CPU solver.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspicey_hip.so")
+_LIB = None
+
+EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "spicey_get_state", "spicey_last_solve_count",
+           "spicey_last_kernel_ms", "spicey_get_info", "spicey_last_error", "spicey_destroy", "spicey_version"]
+
+
+class SpiceyNativeError(RuntimeError):
+    pass
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise SpiceyNativeError(f"{LIB_PATH} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                                "spicey_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    f64p, i32p, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+    L.spicey_create.restype = C.c_int32
+    L.spicey_create.argtypes = [C.POINTER(abi.SpiceyDesc), C.POINTER(abi.SpiceyOptions), C.POINTER(vp)]
+    L.spicey_run.restype = C.c_int32
+    L.spicey_run.argtypes = [vp, C.c_int64, C.c_double, f64p, f64p, f64p, i32p]
+    L.spicey_run_device.restype = C.c_int32
+    L.spicey_run_device.argtypes = [vp, C.c_int64, C.c_double, vp, vp, vp, vp, vp]
+    L.spicey_sync.restype = C.c_int32
+    L.spicey_sync.argtypes = [vp]
+    L.spicey_get_state.restype = C.c_int32
+    L.spicey_get_state.argtypes = [vp, f64p, f64p, f64p, i32p]
+    L.spicey_last_solve_count.restype = C.c_int64
+    L.spicey_last_solve_count.argtypes = [vp]
+    L.spicey_last_kernel_ms.restype = C.c_double
+    L.spicey_last_kernel_ms.argtypes = [vp]
+    L.spicey_get_info.restype = C.c_int32
+    L.spicey_get_info.argtypes = [vp, C.POINTER(abi.SpiceyInfo)]
+    L.spicey_last_error.restype = C.c_char_p
+    L.spicey_last_error.argtypes = [vp]
+    L.spicey_destroy.restype = None
+    L.spicey_destroy.argtypes = [vp]
+    L.spicey_version.restype = C.c_char_p
+    _LIB = L
+    return L
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+class Handle:
+    """Owns one SpiceyHandle (one topology, n_inst instances, one device)."""
+
+    def __init__(self, flat: abi.FlatCircuit, device: int = 0, threads: int = 0, inst_per_wg: int = 0,
+                 force_global: bool = False):
+        self.L = load()
+        self.flat = flat
+        opt = abi.SpiceyOptions()
+        opt.device, opt.threads, opt.inst_per_wg, opt.want_currents, opt.force_global = device, threads, inst_per_wg, 1, int(force_global)
+        d = flat.desc()
+        hp = C.c_void_p()
+        rc = self.L.spicey_create(C.byref(d), C.byref(opt), C.byref(hp))
+        if rc != abi.OK:
+            msg = self.L.spicey_last_error(None)
+            raise SpiceyNativeError(f"spicey_create failed ({rc}): {msg.decode() if msg else ''}")
+        self.h = hp
+
+    def info(self) -> dict:
+        i = abi.SpiceyInfo()
+        self.L.spicey_get_info(self.h, C.byref(i))
+        return i.as_dict()
+
+    def error(self) -> str:
+        m = self.L.spicey_last_error(self.h)
+        return m.decode() if m else ""
+
+    def run(self, steps: int, dt: float, src: np.ndarray, want_currents: bool = True, want_iters: bool = True) -> dict:
+        f = self.flat
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        if src.shape != (steps + 1, f.nV):
+            raise ValueError(f"src_table must be [steps+1][nV] = {(steps + 1, f.nV)}, got {src.shape}")
+        out_v = np.empty((f.n_inst, steps + 1, f.n_out))
+        out_i = np.empty((f.n_inst, steps + 1, f.n_cur)) if want_currents else None
+        iters = np.zeros((f.n_inst, steps + 1), np.int32) if want_iters else None
+        rc = self.L.spicey_run(self.h, steps, dt, _p(src, C.c_double), _p(out_v, C.c_double), _p(out_i, C.c_double),
+                               _p(iters, C.c_int32))
+        res = {"status": rc, "detail": self.error() if rc != abi.OK else "", "out_v": out_v, "out_i": out_i, "iters": iters}
+        if rc == abi.OK:
+            res["state"] = self.state()
+            res["solves"] = self.L.spicey_last_solve_count(self.h)
+            res["kernel_ms"] = self.L.spicey_last_kernel_ms(self.h)
+        return res
+
+    def run_device(self, steps: int, dt: float, d_src: int, d_out_v: int, d_out_i: int = 0, d_iters: int = 0, stream: int = 0) -> None:
+        """Enqueue with raw device pointers (e.g. torch tensors' data_ptr()); no synchronisation."""
+        rc = self.L.spicey_run_device(self.h, steps, dt, d_src, d_out_v, d_out_i or None, d_iters or None, stream or None)
+        if rc != abi.OK:
+            raise SpiceyNativeError(f"spicey_run_device failed ({rc}): {self.error()}")
+
+    def sync(self) -> int:
+        return self.L.spicey_sync(self.h)
+
+    def solves(self) -> int:
+        return self.L.spicey_last_solve_count(self.h)
+
+    def kernel_ms(self) -> float:
+        return self.L.spicey_last_kernel_ms(self.h)
+
+    def state(self) -> dict:
+        f = self.flat
+        st = {"C_vprev": np.zeros((f.n_inst, f.nC)), "L_iprev": np.zeros((f.n_inst, f.nL)), "D_vdprev": np.zeros((f.n_inst, f.nD)),
+              "S_ison": np.zeros((f.n_inst, f.nS), np.int32)}
+        rc = self.L.spicey_get_state(self.h, _p(st["C_vprev"], C.c_double), _p(st["L_iprev"], C.c_double),
+                                     _p(st["D_vdprev"], C.c_double), _p(st["S_ison"], C.c_int32))
+        if rc != abi.OK:
+            raise SpiceyNativeError(f"spicey_get_state failed ({rc}): {self.error()}")
+        return st
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.L.spicey_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipBackend:
+    """Backend interface used by spicey_amd.simulate: one handle per call (the reference API is stateless)."""
+
+    def __init__(self, device: int = 0, threads: int = 0, inst_per_wg: int = 0, force_global: bool = False):
+        self.kw = dict(device=device, threads=threads, inst_per_wg=inst_per_wg, force_global=force_global)
+        self.info: Optional[dict] = None
+
+    def run(self, flat: abi.FlatCircuit, steps: int, dt: float, src: np.ndarray, want_currents: bool = True,
+            want_iters: bool = True) -> dict:
+        h = Handle(flat, **self.kw)
+        try:
+            self.info = h.info()
+            return h.run(steps, dt, src, want_currents, want_iters)
+        finally:
+            h.close()

@@ -70,3 +70,39 @@ def rcd_mesh(rows: int = 100, cols: int | None = None, seed: int = 3, tran: str 
                     lines.append(f"D{i}_{j} m{i}_{j} 0 DM")
     lines += [tran, ".end", ""]
     return "\n".join(lines)
+
+
+def chain_values(n: int, seeds, r0: float, c0: float = 1e-9):
+    """Vectorised LCG draws of rc_ladder / diode_chain for many seeds at once (BASELINE config 4:
+    same topology, per-instance r_k, c_k).  Returns (R[len(seeds)][n-1], C[len(seeds)][n-1]) equal
+    bit for bit to what the netlist text of the same seed parses to."""
+    import numpy as np
+
+    s = np.asarray(list(seeds), dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    R = np.empty((len(s), n - 1))
+    C = np.empty((len(s), n - 1))
+    a, c, m = np.uint64(1664525), np.uint64(1013904223), np.uint64(0xFFFFFFFF)
+    for k in range(n - 1):
+        s = (a * s + c) & m
+        R[:, k] = r0 * (1.0 + 0.1 * (s.astype(np.float64) / 4294967296.0))
+        s = (a * s + c) & m
+        C[:, k] = c0 * (1.0 + 0.1 * (s.astype(np.float64) / 4294967296.0))
+    return R, C
+
+
+def chain_batch(kind: str, n: int, seeds, tran: str = ".tran 1e-6 1e-2"):
+    """FlatCircuit batch of `kind` in {"rc_ladder", "diode_chain"} for the given seeds, plus
+    (dt, steps, src_table).  Topology is parsed once from the netlist text of the first seed."""
+    from . import abi
+    from .netlist import parseNetlist
+
+    seeds = list(seeds)
+    gen = {"rc_ladder": rc_ladder, "diode_chain": diode_chain}[kind]
+    ckt = parseNetlist(gen(n, seed=seeds[0], tran=tran))
+    flat = abi.flatten(ckt).replicate(len(seeds))
+    R, C = chain_values(n, seeds, 10.0 if kind == "rc_ladder" else 100.0)
+    flat.R_val[:, :] = R
+    flat.C_val[:, :] = C
+    tr = ckt.analyses["tran"]
+    dt, steps = abi.computeEffectiveTimeStep(tr["dt"], tr["tstop"])
+    return flat, dt, steps, abi.source_table(ckt, dt, steps)

@@ -1,0 +1,123 @@
+// tests/emul/emul.cpp — CPU emulation of the device program (TEST INFRASTRUCTURE ONLY).
+//
+// Runs the SAME symbolic phase (spicey_amd/csrc/symbolic.cpp) and the SAME phase interpreter
+// (spicey_amd/csrc/tran_exec.h) as the HIP kernel, with `phase(f)` executed as a sequential loop
+// over the thread ids.  It lets the CPU test-suite check ordering, scheduling and the interpreter
+// numerics against the oracle without a GPU, and detects intra-phase races by running the threads
+// of every phase in reverse order too.  It is NOT part of the product and is never loaded by
+// spicey_amd/: libspicey_hip.so has no CPU path.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../spicey_amd/csrc/symbolic.h"
+#include "../../spicey_amd/csrc/tran_exec.h"
+
+namespace {
+struct SeqExec {
+  int T;
+  bool reverse;
+  int threads() const { return T; }
+  template <class F>
+  void phase(F f) {
+    if (!reverse)
+      for (int t = 0; t < T; t++) f(t);
+    else
+      for (int t = T - 1; t >= 0; t--) f(t);
+  }
+};
+
+template <int K>
+void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T, bool reverse) {
+  const int ngroups = (R.n_inst + K - 1) / K;
+  std::vector<double> W((size_t)P.nW * K), u((size_t)(P.nU + 1) * K), gd((size_t)(P.nGdyn + 1) * K);
+  std::vector<int32_t> ison((size_t)(P.nS + 1) * K), flags(4);
+  for (int g = 0; g < ngroups; g++) {
+    WgCtx<K> c;
+    c.W = W.data(); c.u = u.data(); c.gd = gd.data(); c.ison = ison.data(); c.flags = flags.data();
+    for (int k = 0; k < K; k++) {
+      int in = g * K + k;
+      c.valid[k] = in < R.n_inst;
+      c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
+    }
+    SeqExec ex{T, reverse};
+    spicey_tran_run<K>(ex, P, R, c, g);
+  }
+  (void)hp;
+}
+}  // namespace
+
+extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, int64_t steps, double dt, const double *src,
+                                   double *out_v, double *out_i, int32_t *iters, double *C_vprev, double *L_iprev,
+                                   double *D_vdprev, int32_t *S_ison, int32_t reverse, SpiceyInfo *info, int32_t *err4,
+                                   int64_t *solves_out) {
+  HostProgram hp;
+  std::string err;
+  int32_t rc = spicey_build_program(d, hp, err);
+  if (rc != SPICEY_OK) return rc;
+  SpiceyProg P = hp.bind(hp.blob.data());
+  if (info) {
+    memset(info, 0, sizeof(*info));
+    info->n_var = P.n; info->nnz_a = hp.nnzA; info->nnz_lu = P.nLU; info->n_levels = P.nLevels;
+    info->threads = T; info->inst_per_wg = K; info->n_cur = P.nCur; info->n_out = P.nOut;
+    info->program_bytes = (int64_t)hp.blob.size();
+    info->algorithmic_bytes_solve = spicey_algorithmic_bytes(d, hp.nnzA, P.nLU);
+    info->n_workgroups = (d->n_inst + K - 1) / K;
+  }
+  if (hp.structurally_singular) {
+    if (err4) { err4[0] = 1; err4[1] = 0; err4[2] = 0; err4[3] = 0; }
+    return SPICEY_ERR_SINGULAR;
+  }
+  const int ni = d->n_inst;
+  SpiceyRun R{};
+  R.n_inst = ni; R.want_currents = out_i != nullptr; R.steps = steps; R.dt = dt;
+  R.R_val = d->R_val; R.C_val = d->C_val; R.L_val = d->L_val;
+  R.S_ron = d->S_ron; R.S_roff = d->S_roff; R.S_von = d->S_von; R.S_voff = d->S_voff;
+  R.D_is = d->D_is; R.D_n = d->D_n;
+  R.C_vprev = C_vprev; R.L_iprev = L_iprev; R.D_vdprev = D_vdprev; R.S_ison = S_ison;
+  std::vector<double> gstat((size_t)ni * P.nGstat), statv((size_t)ni * P.nLU), rcoef((size_t)ni * (P.nRhsIdx + 1));
+  R.gstat = gstat.data(); R.statv = statv.data(); R.rcoef = rcoef.data();
+  R.src = src; R.out_v = out_v; R.out_i = out_i; R.iters = iters;
+  const int ngroups = (ni + K - 1) / K;
+  std::vector<int32_t> status((size_t)ngroups * 4);
+  std::vector<unsigned long long> solves(ngroups);
+  R.status = status.data(); R.solves = solves.data();
+  if (T <= 0 || (T & 63)) return SPICEY_ERR_BAD_DESC;
+  switch (K) {
+    case 1: run_groups<1>(hp, P, R, T, reverse != 0); break;
+    case 2: run_groups<2>(hp, P, R, T, reverse != 0); break;
+    case 4: run_groups<4>(hp, P, R, T, reverse != 0); break;
+    default: return SPICEY_ERR_BAD_DESC;
+  }
+  int64_t tot = 0;
+  for (int g = 0; g < ngroups; g++) tot += (int64_t)solves[g];
+  if (solves_out) *solves_out = tot;
+  for (int g = 0; g < ngroups; g++)
+    if (status[(size_t)g * 4]) {
+      if (err4) memcpy(err4, &status[(size_t)g * 4], 16);
+      return SPICEY_ERR_SINGULAR;
+    }
+  return SPICEY_OK;
+}
+
+// Expose ordering details for structural tests.
+extern "C" int32_t spicey_emul_symbolic(const SpiceyDesc *d, int32_t *cpos, int32_t *rpos, int32_t *level, SpiceyInfo *info,
+                                        int64_t *products) {
+  HostProgram hp;
+  std::string err;
+  int32_t rc = spicey_build_program(d, hp, err);
+  if (rc != SPICEY_OK) return rc;
+  const int n = hp.hdr.n;
+  if (cpos) memcpy(cpos, hp.cpos.data(), sizeof(int32_t) * n);
+  if (rpos) memcpy(rpos, hp.rpos.data(), sizeof(int32_t) * n);
+  if (level) memcpy(level, hp.level.data(), sizeof(int32_t) * n);
+  if (info) {
+    memset(info, 0, sizeof(*info));
+    info->n_var = n; info->nnz_a = hp.nnzA; info->nnz_lu = hp.hdr.nLU; info->n_levels = hp.hdr.nLevels;
+    info->n_cur = hp.hdr.nCur; info->n_out = hp.hdr.nOut; info->program_bytes = (int64_t)hp.blob.size();
+    info->algorithmic_bytes_solve = spicey_algorithmic_bytes(d, hp.nnzA, hp.hdr.nLU);
+  }
+  if (products) { products[0] = hp.n_products; products[1] = hp.n_bk_products; }
+  return hp.structurally_singular ? SPICEY_ERR_SINGULAR : SPICEY_OK;
+}

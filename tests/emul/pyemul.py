@@ -1,0 +1,74 @@
+"""ctypes front-end of tests/emul/emul.cpp (CPU emulation of the device program; test infrastructure)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from spicey_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.run(["make", "-s", "-C", _HERE], check=True)
+        L = C.CDLL(os.path.join(_HERE, "_build", "libspicey_emul.so"))
+        f64p, i32p, i64p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        L.spicey_emul_run.restype = C.c_int32
+        L.spicey_emul_run.argtypes = [C.POINTER(abi.SpiceyDesc), C.c_int32, C.c_int32, C.c_int64, C.c_double, f64p, f64p, f64p,
+                                      i32p, f64p, f64p, f64p, i32p, C.c_int32, C.POINTER(abi.SpiceyInfo), i32p, i64p]
+        L.spicey_emul_symbolic.restype = C.c_int32
+        L.spicey_emul_symbolic.argtypes = [C.POINTER(abi.SpiceyDesc), i32p, i32p, i32p, C.POINTER(abi.SpiceyInfo), i64p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+class EmulBackend:
+    def __init__(self, K=1, T=256, reverse=False):
+        self.K, self.T, self.reverse = K, T, reverse
+        self.info = None
+        self.solves = None
+
+    def run(self, flat: abi.FlatCircuit, steps: int, dt: float, src: np.ndarray, want_currents: bool = True,
+            want_iters: bool = True) -> dict:
+        L = lib()
+        d = flat.desc()
+        ni = flat.n_inst
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        out_v = np.zeros((ni, steps + 1, flat.n_out))
+        out_i = np.zeros((ni, steps + 1, flat.n_cur)) if want_currents else None
+        iters = np.zeros((ni, steps + 1), np.int32) if want_iters else None
+        st = {"C_vprev": flat.C_vprev.copy(), "L_iprev": flat.L_iprev.copy(), "D_vdprev": flat.D_vdprev.copy(),
+              "S_ison": flat.S_ison.copy()}
+        info = abi.SpiceyInfo()
+        err4 = np.zeros(4, np.int32)
+        solves = C.c_int64(0)
+        rc = L.spicey_emul_run(C.byref(d), self.K, self.T, steps, dt, _p(src, C.c_double), _p(out_v, C.c_double),
+                               _p(out_i, C.c_double), _p(iters, C.c_int32), _p(st["C_vprev"], C.c_double),
+                               _p(st["L_iprev"], C.c_double), _p(st["D_vdprev"], C.c_double), _p(st["S_ison"], C.c_int32),
+                               1 if self.reverse else 0, C.byref(info), _p(err4, C.c_int32), C.byref(solves))
+        self.info = info.as_dict()
+        self.solves = solves.value
+        detail = f"singular at inst {err4[1]} step {err4[2]} iter {err4[3]}" if rc == abi.ERR_SINGULAR else ""
+        return {"status": rc, "detail": detail, "out_v": out_v, "out_i": out_i, "iters": iters, "state": st}
+
+
+def symbolic(flat: abi.FlatCircuit):
+    L = lib()
+    d = flat.desc()
+    n = flat.n_var
+    cpos, rpos, level = (np.zeros(n, np.int32) for _ in range(3))
+    info = abi.SpiceyInfo()
+    prods = np.zeros(2, np.int64)
+    rc = L.spicey_emul_symbolic(C.byref(d), _p(cpos, C.c_int32), _p(rpos, C.c_int32), _p(level, C.c_int32), C.byref(info),
+                                _p(prods, C.c_int64))
+    return rc, cpos, rpos, level, info.as_dict(), prods

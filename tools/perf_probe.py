@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""GPU perf probe: sweep (workload, batch, K, T) and print solves/s (device-resident buffers)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+
+from spicey_amd import synth  # noqa: E402
+from spicey_amd.lib import Handle  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="diode_chain")
+    ap.add_argument("--n", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--configs", default="1:1:512,256:1:512,512:1:512,512:2:512")  # B:K:T
+    ap.add_argument("--currents", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--global", dest="force_global", type=int, default=0)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for cfg in args.configs.split(","):
+        B, K, T = (int(x) for x in cfg.split(":"))
+        flat, dt, _, _ = synth.chain_batch(args.workload, args.n, range(1, B + 1), tran=f".tran 1e-6 {args.steps * 1e-6!r}")
+        from spicey_amd import abi
+        from spicey_amd.netlist import parseNetlist
+        ckt = parseNetlist(getattr(synth, args.workload)(args.n, seed=1, tran=".tran 1e-6 1e-2"))
+        steps = args.steps
+        src = torch.tensor(abi.source_table(ckt, 1e-6, steps), device=dev)
+        h = Handle(flat, threads=T, inst_per_wg=K, force_global=bool(args.force_global))
+        info = h.info()
+        out_v = torch.empty((B, steps + 1, info["n_out"]), dtype=torch.float64, device=dev)
+        out_i = torch.empty((B, steps + 1, info["n_cur"]), dtype=torch.float64, device=dev) if args.currents else None
+        best = None
+        for rep in range(args.reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            h.run_device(steps, 1e-6, src.data_ptr(), out_v.data_ptr(), out_i.data_ptr() if out_i is not None else 0)
+            rc = h.sync()
+            t1 = time.perf_counter()
+            assert rc == 0, h.error()
+            ms = h.kernel_ms()
+            best = ms if best is None else min(best, ms)
+        solves = h.solves()
+        rec = dict(workload=args.workload, n=args.n, B=B, K=info["inst_per_wg"], T=info["threads"], lds=info["lds_bytes"],
+                   steps=steps, kernel_ms=best, solves=solves, solves_per_s=solves / (best * 1e-3), wall_ms=(t1 - t0) * 1e3,
+                   us_per_step=best * 1e3 / (steps + 1), levels=info["n_levels"], nnz_lu=info["nnz_lu"], currents=args.currents,
+                   finite=bool(torch.isfinite(out_v[:, -1]).all().item()))
+        print(json.dumps(rec), flush=True)
+        h.close()
+        del out_v, out_i
+
+
+if __name__ == "__main__":
+    main()
