@@ -1,0 +1,163 @@
+"""CPU checks of the host logic: symbolic phase + device-program interpreter (run through the CPU
+emulator in tests/emul, which executes the same tran_exec.h phases as the HIP kernel), against the
+oracle; plus the C-ABI library's loadability and exported symbols (no compute without a GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import LARGE_GOLDENS, REPO, SMALL_GOLDENS, golden_netlist, load_golden
+from emul.pyemul import EmulBackend, symbolic
+from spicey_amd import abi, synth
+from spicey_amd.netlist import parseNetlist
+
+RTOL, ATOL = 1e-9, 1e-12
+LOOSE = {"bridge_rectifier": 1e-5}  # see tests/test_gpu_parity.py
+
+
+def ratio(got, ref, rtol=RTOL):
+    with np.errstate(invalid="ignore"):
+        r = np.abs(got - ref) / (rtol * np.abs(ref) + ATOL)
+    r = np.where(~np.isfinite(ref) & ((got == ref) | (np.isnan(got) & np.isnan(ref))), 0.0, r)
+    r = np.nan_to_num(r, nan=np.inf)
+    return r if r.size else np.zeros(1)
+
+
+def _inputs(name):
+    ckt = parseNetlist(golden_netlist(load_golden(name)))
+    tr = ckt.analyses["tran"]
+    dt, steps = abi.computeEffectiveTimeStep(tr["dt"], tr["tstop"])
+    return abi.flatten(ckt), steps, dt, abi.source_table(ckt, dt, steps)
+
+
+@pytest.mark.parametrize("name", SMALL_GOLDENS + ["mesh20_30"])
+def test_program_vs_oracle(name, oracle_backend):
+    flat, steps, dt, src = _inputs(name)
+    ref = oracle_backend.run(flat, steps, dt, src)
+    outs = []
+    for T, rev in ((128, False), (64, True)):  # reversed thread order inside every phase: race detector
+        got = EmulBackend(1, T, rev).run(flat, steps, dt, src)
+        assert got["status"] == 0, got["detail"]
+        rtol = LOOSE.get(name, RTOL)
+        assert ratio(got["out_v"], ref["out_v"], rtol).max() <= 1.0
+        assert ratio(got["out_i"], ref["out_i"], rtol).max() <= 1.0
+        assert np.array_equal(got["iters"], ref["iters"])
+        assert np.array_equal(got["state"]["S_ison"], ref["state"]["S_ison"])
+        for k in ("C_vprev", "L_iprev", "D_vdprev"):
+            assert ratio(got["state"][k], ref["state"][k], rtol).max() <= 1.0
+        outs.append(got["out_v"])
+    assert np.array_equal(outs[0], outs[1])  # independent of thread count and order: deterministic
+
+
+@pytest.mark.parametrize("name", ["rc1000_200", "dchain1000_200"])
+def test_program_1000_nodes(name, oracle_backend):
+    flat, steps, dt, src = _inputs(name)
+    steps = 40
+    src = src[: steps + 1]
+    ref = oracle_backend.run(flat, steps, dt, src)
+    be = EmulBackend(1, 512)
+    got = be.run(flat, steps, dt, src)
+    assert ratio(got["out_v"], ref["out_v"]).max() <= 1.0 and ratio(got["out_i"], ref["out_i"]).max() <= 1.0
+    # nested dissection on a ladder = cyclic reduction: ceil(log2(1001)) + 1 levels, < 2x fill
+    assert be.info["n_levels"] <= 12 and be.info["nnz_a"] == 3000 and be.info["nnz_lu"] < 5200
+    assert be.solves == steps + 1
+
+
+@pytest.mark.parametrize("K,T", [(2, 64), (4, 256), (1, 1024)])
+def test_program_batched_instances(K, T, oracle_backend):
+    flat, dt, steps, src = synth.chain_batch("diode_chain", 40, range(1, 8), tran=".tran 1e-6 3e-5")
+    ref = oracle_backend.run(flat, steps, dt, src)
+    be = EmulBackend(K, T)
+    got = be.run(flat, steps, dt, src)
+    assert got["status"] == 0
+    assert ratio(got["out_v"], ref["out_v"]).max() <= 1.0 and ratio(got["out_i"], ref["out_i"]).max() <= 1.0
+    assert be.solves == 7 * (steps + 1)
+
+
+@pytest.mark.parametrize("name", ["err_singular", "err_vloop"])
+def test_program_singular(name):
+    flat, steps, dt, src = _inputs(name)
+    got = EmulBackend(1, 64).run(flat, steps, dt, src)
+    assert got["status"] == abi.ERR_SINGULAR and "step 0 iter 0" in got["detail"]
+
+
+def test_state_continuation(oracle_backend):
+    """Second run continues from the first run's end state."""
+    flat, steps, dt, src = _inputs("half_bridge")
+    be, ob = EmulBackend(1, 64), oracle_backend
+    a1, r1 = be.run(flat, steps, dt, src), ob.run(flat, steps, dt, src)
+    for f_, res in ((flat, a1),):
+        pass
+    import copy
+    fa, fr = copy.deepcopy(flat), copy.deepcopy(flat)
+    for f_, res in ((fa, a1), (fr, r1)):
+        f_.C_vprev[:] = res["state"]["C_vprev"]; f_.L_iprev[:] = res["state"]["L_iprev"]
+        f_.D_vdprev[:] = res["state"]["D_vdprev"]; f_.S_ison[:] = res["state"]["S_ison"]
+    a2, r2 = be.run(fa, steps, dt, src), ob.run(fr, steps, dt, src)
+    assert ratio(a2["out_v"], r2["out_v"]).max() <= 1.0 and np.array_equal(a2["iters"], r2["iters"])
+
+
+def test_symbolic_structure():
+    ckt = parseNetlist(synth.rcd_mesh(12, seed=3, tran=".tran 1e-6 1e-5"))
+    flat = abi.flatten(ckt)
+    rc, cpos, rpos, level, info, prods = symbolic(flat)
+    n = flat.n_var
+    assert rc == 0 and sorted(cpos) == list(range(n)) and sorted(rpos) == list(range(n))
+    # the voltage-source branch equation is matched to its node column, the node's KCL row to the branch column
+    j = flat.n_nodes
+    v_node = flat.V_n1[0] - 1
+    assert rpos[j] == cpos[v_node] and rpos[v_node] == cpos[j]
+    assert info["n_levels"] == level.max() + 1 and info["nnz_lu"] >= info["nnz_a"]
+    assert info["algorithmic_bytes_solve"] == (8 * (3 * info["nnz_a"] + 2 * info["nnz_lu"]) + 4 * (info["nnz_a"] + info["nnz_lu"])
+                                               + 32 * n + 16 * (flat.nC + flat.nL + flat.nD) + 8 * (flat.n_nodes + flat.n_cur))
+
+
+def test_algorithmic_bytes_match_survey():
+    """config 2 = 216 048 B, config 3 = 240 024 B per solve (with the survey's nnz(L+U) = 3002)."""
+    for gen, want in ((synth.rc_ladder, 216048), (synth.diode_chain, 240024)):
+        flat = abi.flatten(parseNetlist(gen(1000)))
+        n, nnzA, nnzLU = flat.n_var, 3000, 3002
+        b = 8 * (3 * nnzA + 2 * nnzLU) + 4 * (nnzA + nnzLU) + 32 * n + 16 * (flat.nC + flat.nL + flat.nD) + 8 * (flat.n_nodes + flat.n_cur)
+        assert b == want
+
+
+def test_abi_library_exports_header_symbols():
+    """libspicey_hip.so loads and exports every function include/spicey_hip.h declares."""
+    import ctypes
+    from spicey_amd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    hdr = open(os.path.join(REPO, "include", "spicey_hip.h")).read()
+    declared = set(re.findall(r"\b(spicey_[a-z_]+)\s*\(", hdr))
+    assert declared == set(lib.EXPORTS)
+    L = ctypes.CDLL(lib.LIB_PATH)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert b"gfx950" in lib.load().spicey_version()
+
+
+def test_no_gpu_fails_loudly():
+    """The product path has no CPU fallback: without a device spicey_create reports NO_DEVICE."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from spicey_amd.lib import Handle, SpiceyNativeError
+    flat = abi.flatten(parseNetlist(synth.rc_ladder(8)))
+    with pytest.raises(SpiceyNativeError, match="no HIP device"):
+        Handle(flat)
+    from spicey_amd.simulate import simulate
+    with pytest.raises(SpiceyNativeError):
+        simulate(synth.rc_ladder(8))
+
+
+def test_product_does_not_touch_oracle():
+    """No file of the shipped package imports, loads or links anything under oracle/ or tests/."""
+    pkg = os.path.join(REPO, "spicey_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"(from|import)\s+oracle|oracle/|pyoracle|liboracle|tests/emul|pyemul", text.replace("tests/emul)", "")) \
+                    or f in ("tran_exec.h",), (root, f)
