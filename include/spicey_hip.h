@@ -84,7 +84,9 @@ typedef struct SpiceyOptions {
   int32_t inst_per_wg;   /* instances interleaved in one workgroup's LDS, 0 = auto */
   int32_t want_currents; /* 1: record element currents (out_i) */
   int32_t force_global;  /* 1: keep the LU workspace in HBM/L2 even if it fits LDS (testing) */
-  int32_t reserved[3];
+  int32_t profile;       /* 1: accumulate per-phase shader-clock cycles (spicey_debug_phase_cycles) */
+  int32_t interpreter;   /* 0 auto; 1 = v1 (32-bit sliced task lists from L2); 2 = v2 (register-resident 16-bit records) */
+  int32_t reserved[1];
 } SpiceyOptions;
 
 typedef struct SpiceyInfo {
@@ -98,6 +100,10 @@ typedef struct SpiceyInfo {
   int32_t n_cur;       /* element-current columns */
   int32_t n_out;       /* recorded node-voltage columns */
   int32_t n_workgroups;
+  int32_t interpreter;      /* 1 or 2, see SpiceyOptions */
+  int32_t resident_slots;   /* v2: 16-byte task records per thread kept in VGPRs */
+  int64_t resident_tasks;   /* v2: factor/backward tasks held in registers */
+  int64_t streamed_tasks;   /* v2: tasks still fetched from L2 every step */
   int64_t program_bytes;            /* device-side schedule ("program") size */
   int64_t algorithmic_bytes_solve;  /* SURVEY.md §8(d) formula */
 } SpiceyInfo;
@@ -142,6 +148,11 @@ int32_t spicey_get_info(SpiceyHandle *h, SpiceyInfo *info);
  * hipGetErrorString text, …).  Valid until the next call on the handle. NULL handle -> global. */
 const char *spicey_last_error(SpiceyHandle *h);
 void spicey_destroy(SpiceyHandle *h);
+
+/* Diagnostics: shader-clock cycles spent per phase kind by workgroup 0 during the last run (needs
+ * SpiceyOptions.profile = 1).  out[72]: [0] prologue, [1] B stamp+rhs, [2] S switches, [3] A re-linearise,
+ * [4] Z record/next-eval, [8+l] factor level l, [40+l] backward level l.  Returns the slot count. */
+int32_t spicey_debug_phase_cycles(SpiceyHandle *h, uint64_t *out, int32_t n);
 
 /* Library build info: "spicey_hip <abi> gfx950 …" */
 const char *spicey_version(void);

@@ -10,3 +10,8 @@
 size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds);
 size_t spicey_gw_doubles_per_wg(const SpiceyProg &P, int K);
 hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bool lds, int grid, int threads, hipStream_t st);
+
+// v2 (register-resident program): slots per thread for a workgroup size, and the launcher (K in {1, 2})
+int spicey_v2_rmax(int threads);
+hipError_t spicey_launch_tran_v2(const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, int K, int grid, int threads,
+                                 hipStream_t st);

@@ -17,11 +17,15 @@
 namespace {
 
 struct GpuExec {
+  unsigned long long *prof;  // null unless phase profiling was requested
   __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
   template <class F>
-  __device__ __forceinline__ void phase(F f) {
+  __device__ __forceinline__ void phase(int tag, F f) {
+    long long t0 = 0;
+    if (prof && threadIdx.x == 0) t0 = clock64();
     f((int)threadIdx.x);
     __syncthreads();
+    if (prof && threadIdx.x == 0) prof[tag] += (unsigned long long)(clock64() - t0);
   }
 };
 
@@ -51,8 +55,62 @@ __global__ void __launch_bounds__(1024) spicey_tran_kernel(SpiceyProg P, SpiceyR
     c.valid[k] = in < R.n_inst;
     c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
   }
-  GpuExec ex;
+  GpuExec ex{R.prof ? R.prof + (size_t)wg * SPICEY_PH_SLOTS : nullptr};
   spicey_tran_run<K>(ex, P, R, c, wg);
+}
+
+// v2: register-resident program (LDS workspace only; 16-bit records)
+template <int RMAX>
+struct GpuExecV2 {
+  unsigned long long *prof;
+  ResRegs<RMAX> rr;
+  __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
+  template <int R2>
+  __device__ __forceinline__ ResRegs<R2> &regs(int) {
+    static_assert(R2 == RMAX, "resident slot count mismatch");
+    return rr;
+  }
+  template <class F>
+  __device__ __forceinline__ void phase(int tag, F f) {
+    long long t0 = 0;
+    if (prof && threadIdx.x == 0) t0 = clock64();
+    f((int)threadIdx.x);
+    __syncthreads();
+    if (prof && threadIdx.x == 0) prof[tag] += (unsigned long long)(clock64() - t0);
+  }
+};
+
+template <int K, int RMAX, int MAXT>
+__global__ void __launch_bounds__(MAXT) spicey_tran_kernel_v2(SpiceyProg P, SpiceyResident Q, SpiceyRun R) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  WgCtx<K> c;
+  const int wg = (int)blockIdx.x;
+  const size_t nW = (size_t)P.nW * K, nU = (size_t)P.nU * K, nG = (size_t)P.nGdyn * K;
+  c.W = (double *)smem;
+  c.u = c.W + nW;
+  c.gd = c.u + nU;
+  c.ison = (int32_t *)(c.gd + nG);
+  c.flags = c.ison + (size_t)P.nS * K;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int in = wg * K + k;
+    c.valid[k] = in < R.n_inst;
+    c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
+  }
+  GpuExecV2<RMAX> ex;
+  ex.prof = R.prof ? R.prof + (size_t)wg * SPICEY_PH_SLOTS : nullptr;
+  spicey_tran_run_v2<K, RMAX>(ex, P, Q, R, c, wg);
+}
+
+template <int K, int RMAX, int MAXT>
+hipError_t launch_v2_t(const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, int grid, int threads, size_t lds, hipStream_t st) {
+  auto kern = spicey_tran_kernel_v2<K, RMAX, MAXT>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, Q, R);
+  return hipGetLastError();
 }
 
 template <int K, bool LDS>
@@ -91,6 +149,25 @@ hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bo
       case 1: return launch_t<1, false>(P, R, grid, threads, bytes, st);
       case 2: return launch_t<2, false>(P, R, grid, threads, bytes, st);
       case 4: return launch_t<4, false>(P, R, grid, threads, bytes, st);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
+int spicey_v2_rmax(int threads) { return threads <= 512 ? 16 : 8; }
+
+hipError_t spicey_launch_tran_v2(const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, int K, int grid, int threads,
+                                 hipStream_t st) {
+  const size_t bytes = spicey_lds_bytes(P, K, true);
+  if (threads <= 512) {
+    switch (K) {
+      case 1: return launch_v2_t<1, 16, 512>(P, Q, R, grid, threads, bytes, st);
+      case 2: return launch_v2_t<2, 16, 512>(P, Q, R, grid, threads, bytes, st);
+    }
+  } else {
+    switch (K) {
+      case 1: return launch_v2_t<1, 8, 1024>(P, Q, R, grid, threads, bytes, st);
+      case 2: return launch_v2_t<2, 8, 1024>(P, Q, R, grid, threads, bytes, st);
     }
   }
   return hipErrorInvalidValue;

@@ -24,6 +24,11 @@
 #define SPICEY_TGT_RECIP 0x80000000u  // diagonal becomes final in this task: store 1/pivot, check singularity
 #define SPICEY_TGT_PAD 0x7fffffffu    // padding lane of a slice
 
+// flags of a 16-bit task record (meta bits 8..15)
+#define SPICEY_R16_VALID 0x80u
+#define SPICEY_R16_RECIP 0x02u
+#define SPICEY_R16_K 0x01u
+
 struct SpiceySlice {
   uint32_t off;  // offset (in uint32 words) of the slice's index block inside `pairs`
   uint32_t len;  // longest task of the slice (number of products)
@@ -73,10 +78,37 @@ struct SpiceyProg {
   const uint32_t *bk_pairs;     // per slice: [len][2][64]  (U entry, W index of x'[b])
   int32_t nBkSlices;
 
+  // --- compact 16-bit task records (LDS path: nW < 65536 always holds there) ---------------------
+  // One 16-byte record per update / backward task; phases in execution order:
+  //   phase p in [0, nLevels)          = factor level p          (U task)
+  //   phase p in [nLevels, 2 nLevels)  = backward level 2 nLevels-1-p  (K task)
+  // w0 = tgt | meta<<16, meta = cnt (8 bits) | flags<<8 (SPICEY_R16_*).
+  //   U, cnt<=2: w1 = l0|d0<<16, w2 = u0|l1<<16, w3 = d1|u1<<16 ; cnt>2: w3 = offset of cnt triplets in ovf16
+  //   K        : w1 = d|u0<<16,  w2 = x0|u1<<16, w3 = x1        ; cnt>2: w3 = offset of cnt pairs in ovf16
+  const uint32_t *rec16;     // [nRec16][4]
+  const uint16_t *ovf16;
+  const uint32_t *ph_first;  // [2 nLevels]
+  const uint32_t *ph_cnt;    // [2 nLevels]
+  int32_t nRec16;
+  int32_t has16;             // 0 when nW >= 65536 (global-workspace path only)
+
   // --- elements: terminal positions in W (x' slots), -1 = ground
   const int32_t *R_a, *R_b, *C_a, *C_b, *L_a, *L_b, *S_a, *S_b, *S_cp, *S_cn, *D_a, *D_b;
   const int32_t *V_x;   // [nV] W index of the branch current
   const int32_t *out_x; // [nOut] W index of each recorded node voltage
+};
+
+// Register-resident part of the program, built for one workgroup size T (spicey_build_resident):
+// res[slot][T] records live in VGPRs for the whole run; every (wave, slot) chunk belongs to ONE
+// phase (res_phase[wave][slot], -1 = unused) so the per-phase dispatch is wave-uniform.  Phases that
+// did not fit stay streamed: st_first/st_cnt index rec16.
+struct SpiceyResident {
+  const uint32_t *res;        // [RMAX][T][4]
+  const int32_t *res_phase;   // [T/64][RMAX]
+  const uint32_t *st_first;   // [2 nLevels]
+  const uint32_t *st_cnt;     // [2 nLevels]
+  int32_t rmax;
+  int32_t T;
 };
 
 // Per-run, per-instance data (device pointers; instance-major arrays)
@@ -106,4 +138,5 @@ struct SpiceyRun {
   // status: [n_workgroups][4] = {code, inst, step, iter}; solve counts [n_workgroups]
   int32_t *status;
   unsigned long long *solves;
+  unsigned long long *prof;  // optional [n_workgroups][SPICEY_PH_SLOTS] shader-clock cycles per phase kind (diagnostics)
 };

@@ -15,7 +15,11 @@
 
 struct SpiceyHandle {
   HostProgram hp;
+  HostResident hres;
   SpiceyProg dprog{};
+  SpiceyResident dres{};
+  int interp = 1;
+  void *d_res = nullptr;
   SpiceyOptions opt{};
   int n_inst = 0, n_nodes = 0;
   int K = 1, T = 256, grid = 1;
@@ -32,6 +36,7 @@ struct SpiceyHandle {
   double *d_gstat = nullptr, *d_statv = nullptr, *d_rcoef = nullptr, *d_gW = nullptr;
   int32_t *d_status = nullptr;
   unsigned long long *d_solves = nullptr;
+  unsigned long long *d_prof = nullptr;
   hipStream_t stream = nullptr;  // owned stream for spicey_run
   hipStream_t last_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -69,8 +74,8 @@ extern "C" const char *spicey_last_error(SpiceyHandle *h) { return h ? h->err.c_
 extern "C" void spicey_destroy(SpiceyHandle *h) {
   if (!h) return;
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
-  void *ptrs[] = {h->d_blob, h->d_R, h->d_C, h->d_L, h->d_Sron, h->d_Sroff, h->d_Svon, h->d_Svoff, h->d_Dis, h->d_Dn, h->d_Cv,
-                  h->d_Li, h->d_Dv, h->d_Son, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_status, h->d_solves};
+  void *ptrs[] = {h->d_res, h->d_blob, h->d_R, h->d_C, h->d_L, h->d_Sron, h->d_Sroff, h->d_Svon, h->d_Svoff, h->d_Dis, h->d_Dn, h->d_Cv,
+                  h->d_Li, h->d_Dv, h->d_Son, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_status, h->d_solves, h->d_prof};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -148,6 +153,11 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   if (h->T > 1024 || (h->T & 63)) { h->err = "threads must be a multiple of 64, <= 1024"; return fail(SPICEY_ERR_BAD_DESC); }
   h->grid = (h->n_inst + K - 1) / K;
   h->lds_bytes = spicey_lds_bytes(P, K, h->lds);
+  // interpreter: v2 needs the LDS workspace, 16-bit records and K <= 2
+  const bool v2_ok = h->lds && P.has16 && K <= 2;
+  if (h->opt.interpreter == 2 && !v2_ok) { h->err = "interpreter 2 needs the LDS workspace, < 65536 workspace entries and inst_per_wg <= 2"; return fail(SPICEY_ERR_BAD_DESC); }
+  h->interp = (h->opt.interpreter == 1 || !v2_ok) ? 1 : 2;
+  if (h->interp == 2) spicey_build_resident(h->hp, h->T, spicey_v2_rmax(h->T), h->hres);
 
   // ---- uploads -----------------------------------------------------------------------------------
   const size_t ni = (size_t)h->n_inst;
@@ -157,6 +167,14 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
     return fail(SPICEY_ERR_HIP);
   }
   h->dprog = h->hp.bind(h->d_blob);
+  if (h->interp == 2) {
+    if (hipMalloc(&h->d_res, h->hres.blob.size()) != hipSuccess ||
+        hipMemcpy(h->d_res, h->hres.blob.data(), h->hres.blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      h->err = "upload of the resident program failed";
+      return fail(SPICEY_ERR_HIP);
+    }
+    h->dres = h->hres.bind(h->d_res);
+  }
 #define UP(dst, src, cnt) \
   if ((rc = upload(h, &h->dst, desc->src, (cnt))) != SPICEY_OK) return fail(rc)
   UP(d_R, R_val, ni * P.nR);
@@ -183,6 +201,8 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   if ((rc = upload(h, &h->d_status, noint, (size_t)h->grid * 4)) != SPICEY_OK) return fail(rc);
   const unsigned long long *noull = nullptr;
   if ((rc = upload(h, &h->d_solves, noull, (size_t)h->grid)) != SPICEY_OK) return fail(rc);
+  if (h->opt.profile)
+    if ((rc = upload(h, &h->d_prof, noull, (size_t)h->grid * 72)) != SPICEY_OK) return fail(rc);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     h->err = "stream/event creation failed";
     return fail(SPICEY_ERR_HIP);
@@ -204,6 +224,10 @@ extern "C" int32_t spicey_get_info(SpiceyHandle *h, SpiceyInfo *info) {
   info->n_cur = h->hp.hdr.nCur;
   info->n_out = h->hp.hdr.nOut;
   info->n_workgroups = h->grid;
+  info->interpreter = h->interp;
+  info->resident_slots = h->interp == 2 ? h->hres.rmax : 0;
+  info->resident_tasks = h->hres.resident_tasks;
+  info->streamed_tasks = h->hres.streamed_tasks;
   info->program_bytes = (int64_t)h->hp.blob.size();
   info->algorithmic_bytes_solve = h->algo_bytes;
   return SPICEY_OK;
@@ -230,9 +254,11 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   R.C_vprev = h->d_Cv; R.L_iprev = h->d_Li; R.D_vdprev = h->d_Dv; R.S_ison = h->d_Son;
   R.gstat = h->d_gstat; R.statv = h->d_statv; R.rcoef = h->d_rcoef; R.gW = h->d_gW;
   R.src = d_src_table; R.out_v = d_out_v; R.out_i = d_out_i; R.iters = d_iters;
-  R.status = h->d_status; R.solves = h->d_solves;
+  R.status = h->d_status; R.solves = h->d_solves; R.prof = h->d_prof;
+  if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, (size_t)h->grid * 72 * sizeof(unsigned long long), st));
   HIPCHK(h, hipEventRecord(h->ev0, st));
-  HIPCHK(h, spicey_launch_tran(h->dprog, R, h->K, h->lds, h->grid, h->T, st));
+  if (h->interp == 2) HIPCHK(h, spicey_launch_tran_v2(h->dprog, h->dres, R, h->K, h->grid, h->T, st));
+  else HIPCHK(h, spicey_launch_tran(h->dprog, R, h->K, h->lds, h->grid, h->T, st));
   HIPCHK(h, hipEventRecord(h->ev1, st));
   h->pending = true;
   h->last_stream = st;
@@ -328,3 +354,14 @@ extern "C" int32_t spicey_get_state(SpiceyHandle *h, double *C_vprev, double *L_
 
 extern "C" int64_t spicey_last_solve_count(SpiceyHandle *h) { return h ? h->last_solves : 0; }
 extern "C" double spicey_last_kernel_ms(SpiceyHandle *h) { return h ? h->last_ms : 0.0; }
+
+extern "C" int32_t spicey_debug_phase_cycles(SpiceyHandle *h, uint64_t *out, int32_t n) {
+  if (!h || !out) return 0;
+  for (int i = 0; i < n; i++) out[i] = 0;
+  if (!h->d_prof) return 0;
+  if (spicey_sync(h) == SPICEY_ERR_HIP) return 0;
+  unsigned long long tmp[72];
+  if (hipMemcpy(tmp, h->d_prof, sizeof(tmp), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  for (int i = 0; i < n && i < 72; i++) out[i] = tmp[i];
+  return 72;
+}

@@ -610,6 +610,81 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
   }
   hp.hdr.nBkSlices = (int32_t)hp.bk_slice.size();
 
+  // ---- 5c'. compact 16-bit records of the same tasks, phases in execution order -------------------
+  hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear();
+  hp.hdr.has16 = (nLU + n) < 65536 ? 1 : 0;
+  if (hp.hdr.has16) {
+    auto emit_u = [&](uint32_t tgt, bool recip, const std::vector<uint32_t> &tr) {  // tr = (l,d,u)*
+      const uint32_t cnt = (uint32_t)(tr.size() / 3);
+      uint32_t flags = SPICEY_R16_VALID | (recip ? SPICEY_R16_RECIP : 0u);
+      uint32_t w0 = tgt | ((std::min(cnt, 255u) | (flags << 8)) << 16), w1 = 0, w2 = 0, w3 = 0;
+      if (cnt <= 2) {
+        if (cnt >= 1) { w1 = tr[0] | (tr[1] << 16); w2 = tr[2]; }
+        if (cnt == 2) { w2 |= tr[3] << 16; w3 = tr[4] | (tr[5] << 16); }
+      } else {
+        w3 = (uint32_t)hp.ovf16.size();
+        for (uint32_t v : tr) hp.ovf16.push_back((uint16_t)v);
+      }
+      hp.rec16.insert(hp.rec16.end(), {w0, w1, w2, w3});
+    };
+    auto emit_k = [&](uint32_t x, uint32_t dg, const std::vector<uint32_t> &pr) {  // pr = (u,xb)*
+      const uint32_t cnt = (uint32_t)(pr.size() / 2);
+      uint32_t flags = SPICEY_R16_VALID | SPICEY_R16_K;
+      uint32_t w0 = x | ((std::min(cnt, 255u) | (flags << 8)) << 16), w1 = dg, w2 = 0, w3 = 0;
+      if (cnt <= 2) {
+        if (cnt >= 1) { w1 |= pr[0] << 16; w2 = pr[1]; }
+        if (cnt == 2) { w2 |= pr[2] << 16; w3 = pr[3]; }
+      } else {
+        w3 = (uint32_t)hp.ovf16.size();
+        for (uint32_t v : pr) hp.ovf16.push_back((uint16_t)v);
+      }
+      hp.rec16.insert(hp.rec16.end(), {w0, w1, w2, w3});
+    };
+    bool too_long = false;
+    for (int l = 0; l < nLevels; l++) {  // factor phases: re-derive the grouped tasks of level l
+      hp.ph_first.push_back((uint32_t)(hp.rec16.size() / 4));
+      struct Prod { uint32_t tgt, l, d, u; };
+      std::vector<Prod> prods;
+      for (int k : by_level[l])
+        for (int a : upper[k]) {
+          uint32_t le = (uint32_t)E.find(a, k);
+          for (int b : upper[k]) prods.push_back({(uint32_t)E.find(a, b), le, (uint32_t)diag[k], (uint32_t)E.find(k, b)});
+          prods.push_back({(uint32_t)(nLU + a), le, (uint32_t)diag[k], (uint32_t)(nLU + k)});
+        }
+      std::stable_sort(prods.begin(), prods.end(), [](const Prod &x, const Prod &y) { return x.tgt < y.tgt; });
+      for (size_t i = 0; i < prods.size();) {
+        size_t j = i;
+        std::vector<uint32_t> tr;
+        while (j < prods.size() && prods[j].tgt == prods[i].tgt) { tr.push_back(prods[j].l); tr.push_back(prods[j].d); tr.push_back(prods[j].u); j++; }
+        uint32_t t = prods[i].tgt;
+        bool recip = false;
+        if ((int)t < nLU) {
+          int r = (int)(std::upper_bound(E.ptr.begin(), E.ptr.end(), (int)t) - E.ptr.begin()) - 1;
+          recip = E.col[t] == r && hp.level[r] == l + 1;
+        }
+        if (tr.size() / 3 > 255) too_long = true;
+        emit_u(t, recip, tr);
+        i = j;
+      }
+      hp.ph_cnt.push_back((uint32_t)(hp.rec16.size() / 4) - hp.ph_first.back());
+    }
+    for (int l = nLevels - 1; l >= 0; l--) {  // backward phases, top level first
+      hp.ph_first.push_back((uint32_t)(hp.rec16.size() / 4));
+      for (int k : by_level[l]) {
+        std::vector<uint32_t> pr;
+        for (int b : upper[k]) { pr.push_back((uint32_t)E.find(k, b)); pr.push_back((uint32_t)(nLU + b)); }
+        if (pr.size() / 2 > 255) too_long = true;
+        emit_k((uint32_t)(nLU + k), (uint32_t)diag[k], pr);
+      }
+      hp.ph_cnt.push_back((uint32_t)(hp.rec16.size() / 4) - hp.ph_first.back());
+    }
+    if (too_long || hp.ovf16.size() >= (size_t)1 << 31) {  // count field is 8 bits: such circuits use the 32-bit path
+      hp.hdr.has16 = 0;
+      hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear();
+    }
+  }
+  hp.hdr.nRec16 = (int32_t)(hp.rec16.size() / 4);
+
   // ---- 5d. element terminals and outputs as W indices -------------------------------------------
   auto xpos = [&](int node) -> int32_t { return node == 0 ? -1 : (int32_t)(nLU + hp.cpos[node - 1]); };
   auto map2 = [&](const int32_t *a, const int32_t *b, int cnt, std::vector<int32_t> &oa, std::vector<int32_t> &ob) {
@@ -662,6 +737,10 @@ void HostProgram::pack() {
   add_section(blob, offsets, D_a); add_section(blob, offsets, D_b);    // 30 31
   add_section(blob, offsets, V_x);    // 32
   add_section(blob, offsets, out_x);  // 33
+  add_section(blob, offsets, rec16);     // 34
+  add_section(blob, offsets, ovf16);     // 35
+  add_section(blob, offsets, ph_first);  // 36
+  add_section(blob, offsets, ph_cnt);    // 37
 }
 
 SpiceyProg HostProgram::bind(const void *base) const {
@@ -679,5 +758,69 @@ SpiceyProg HostProgram::bind(const void *base) const {
   p.R_a = i32(20); p.R_b = i32(21); p.C_a = i32(22); p.C_b = i32(23); p.L_a = i32(24); p.L_b = i32(25);
   p.S_a = i32(26); p.S_b = i32(27); p.S_cp = i32(28); p.S_cn = i32(29); p.D_a = i32(30); p.D_b = i32(31);
   p.V_x = i32(32); p.out_x = i32(33);
+  p.rec16 = u32(34); p.ovf16 = (const uint16_t *)(b + offsets[35]); p.ph_first = u32(36); p.ph_cnt = u32(37);
   return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resident layout: chunks of 64 lanes; chunk c lives in (wave c % nWaves, slot c / nWaves), so the
+// chunks of one phase spread over the waves.  Smallest phases first (they are pure latency).
+void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident &out) {
+  out = HostResident();
+  out.rmax = rmax; out.T = T;
+  const int nPh = (int)hp.ph_cnt.size();
+  const int nWaves = T / 64;
+  out.res.assign((size_t)rmax * T * 4, 0u);
+  out.res_phase.assign((size_t)nWaves * rmax, -1);
+  out.st_first.assign(std::max(nPh, 1), 0u);
+  out.st_cnt.assign(std::max(nPh, 1), 0u);
+  if (hp.hdr.has16) {
+    std::vector<int> order(nPh);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return hp.ph_cnt[a] < hp.ph_cnt[b]; });
+    int next_chunk = 0;
+    const int total_chunks = nWaves * rmax;
+    for (int p : order) {
+      const int cnt = (int)hp.ph_cnt[p];
+      const int need = (cnt + 63) / 64;
+      if (cnt == 0) continue;
+      if (next_chunk + need > total_chunks) {  // stays streamed
+        out.st_first[p] = hp.ph_first[p];
+        out.st_cnt[p] = hp.ph_cnt[p];
+        out.streamed_tasks += cnt;
+        continue;
+      }
+      for (int i = 0; i < cnt; i++) {
+        const int c = next_chunk + i / 64, wave = c % nWaves, slot = c / nWaves, lane = i % 64;
+        const size_t dst = ((size_t)slot * T + (size_t)wave * 64 + lane) * 4;
+        const size_t src = ((size_t)hp.ph_first[p] + i) * 4;
+        for (int w = 0; w < 4; w++) out.res[dst + w] = hp.rec16[src + w];
+      }
+      for (int c = next_chunk; c < next_chunk + need; c++) out.res_phase[(size_t)(c % nWaves) * rmax + c / nWaves] = p;
+      next_chunk += need;
+      out.resident_tasks += cnt;
+    }
+  }
+  out.pack();
+}
+
+void HostResident::pack() {
+  blob.clear();
+  offsets.clear();
+  add_section(blob, offsets, res);
+  add_section(blob, offsets, res_phase);
+  add_section(blob, offsets, st_first);
+  add_section(blob, offsets, st_cnt);
+}
+
+SpiceyResident HostResident::bind(const void *base) const {
+  SpiceyResident r{};
+  const uint8_t *b = (const uint8_t *)base;
+  r.res = (const uint32_t *)(b + offsets[0]);
+  r.res_phase = (const int32_t *)(b + offsets[1]);
+  r.st_first = (const uint32_t *)(b + offsets[2]);
+  r.st_cnt = (const uint32_t *)(b + offsets[3]);
+  r.rmax = rmax;
+  r.T = T;
+  return r;
 }

@@ -27,6 +27,8 @@ struct HostProgram {
   std::vector<SpiceySlice> upd_slice;
   std::vector<uint32_t> bk_lvl_slice, bk_x, bk_d, bk_cnt, bk_pairs;
   std::vector<SpiceySlice> bk_slice;
+  std::vector<uint32_t> rec16, ph_first, ph_cnt;  // compact records (has16)
+  std::vector<uint16_t> ovf16;
   std::vector<int32_t> R_a, R_b, C_a, C_b, L_a, L_b, S_a, S_b, S_cp, S_cn, D_a, D_b, V_x, out_x;
 
   // Serialise all arrays into one blob (16-byte aligned sections) and return a SpiceyProg whose
@@ -41,6 +43,20 @@ struct HostProgram {
 // A structurally singular matrix is not an error here: hp.structurally_singular is set and the
 // run reports SPICEY_ERR_SINGULAR, like the reference throws at the first solve.
 int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err);
+
+// Resident (register) layout of the compact records for a workgroup of T threads with `rmax` slots per
+// thread.  Blob sections: res[rmax][T][4] u32, res_phase[T/64][rmax] i32, st_first[2L] u32, st_cnt[2L] u32.
+struct HostResident {
+  std::vector<uint32_t> res, st_first, st_cnt;
+  std::vector<int32_t> res_phase;
+  int rmax = 0, T = 0;
+  int64_t resident_tasks = 0, streamed_tasks = 0;
+  std::vector<uint8_t> blob;
+  std::vector<size_t> offsets;
+  void pack();
+  SpiceyResident bind(const void *base) const;
+};
+void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident &out);
 
 // SURVEY.md §8(d) algorithmic bytes per solve.
 int64_t spicey_algorithmic_bytes(const SpiceyDesc *d, int32_t nnzA, int32_t nnzLU);

@@ -28,6 +28,27 @@
 #else
 #define SPICEY_HD inline
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SPICEY_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)  // value is wave-uniform by construction
+// Keeps a register-resident packed word packed: without this hipcc hoists the field decode (8+ VGPRs and
+// a mask pair per record) out of the time loop and spills.
+#define SPICEY_OPAQUE(x) asm volatile("" : "+v"(x))
+#define SPICEY_NOUNROLL _Pragma("unroll 1")  // thread-strided loops run 1-2 trips: unrolling only costs VGPRs
+#else
+#define SPICEY_NOUNROLL
+#define SPICEY_UNIFORM(x) (x)
+#define SPICEY_OPAQUE(x) (void)(x)
+#endif
+
+// phase tags (profiling slots, SpiceyRun::prof)
+#define SPICEY_PH_PRO 0
+#define SPICEY_PH_B 1
+#define SPICEY_PH_S 2
+#define SPICEY_PH_A 3
+#define SPICEY_PH_Z 4
+#define SPICEY_PH_U0 8
+#define SPICEY_PH_K0 40
+#define SPICEY_PH_SLOTS 72
 
 template <int K>
 struct WgCtx {
@@ -77,6 +98,7 @@ struct TranPhases {
       if (!c.valid[k]) continue;
       const size_t in = (size_t)c.inst[k];
       double *g = R.gstat + in * P.nGstat;
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nGstat; i += T) {
         double v;
         if (i < P.nR) v = 1.0 / R.R_val[in * P.nR + i];
@@ -93,6 +115,7 @@ struct TranPhases {
       const size_t in = (size_t)c.inst[k];
       const double *g = R.gstat + in * P.nGstat;
       double *sv = R.statv + in * P.nLU;
+      SPICEY_NOUNROLL
       for (int e = tid; e < P.nLU; e += T) {
         double v = 0.0;
         for (uint32_t j = P.stat_ptr[e]; j < P.stat_ptr[e + 1]; j++) {
@@ -107,6 +130,7 @@ struct TranPhases {
         sv[e] = v;
       }
       double *rc = R.rcoef + in * P.nRhsIdx;
+      SPICEY_NOUNROLL
       for (int j = tid; j < P.nRhsIdx; j += T) rc[j] = g[P.rhs_cof[j]];
     }
   }
@@ -115,14 +139,19 @@ struct TranPhases {
     const int oL = P.nC, oV = P.nC + P.nL, oD = P.nC + P.nL + P.nV;
     for (int k = 0; k < K; k++) {
       const size_t in = (size_t)c.inst[k];
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nC; i += T) c.u[(size_t)i * K + k] = R.C_vprev[in * P.nC + i];
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nL; i += T) c.u[(size_t)(oL + i) * K + k] = R.L_iprev[in * P.nL + i];
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nV; i += T) c.u[(size_t)(oV + i) * K + k] = R.src[i];
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nS; i += T) {
         const int on = R.S_ison[in * P.nS + i];
         c.ison[(size_t)i * K + k] = on;
         c.gd[(size_t)i * K + k] = spicey_switch_g(on, R.S_ron[in * P.nS + i], R.S_roff[in * P.nS + i]);
       }
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nD; i += T) {
         double g, q;
         spicey_diode(R.D_vdprev[in * P.nD + i], R.D_is[in * P.nD + i], R.D_n[in * P.nD + i], g, q);
@@ -136,6 +165,7 @@ struct TranPhases {
   SPICEY_HD void static_copy(int tid) const {
     for (int k = 0; k < K; k++) {
       const double *sv = R.statv + (size_t)c.inst[k] * P.nLU;
+      SPICEY_NOUNROLL
       for (int e = tid; e < P.nLU; e += T) c.W[(size_t)e * K + k] = sv[e];
     }
   }
@@ -143,6 +173,7 @@ struct TranPhases {
   // ---- B: dynamic stamps + right-hand side ----------------------------------------------------
   SPICEY_HD void b_stamp(int tid) const {
     if (tid == 0) c.flags[0] = 0;
+    SPICEY_NOUNROLL
     for (int t = tid; t < P.nDynEnt; t += T) {
       const uint32_t et = P.dyn_ent[t];
       const uint32_t e = SPICEY_IDX(et);
@@ -161,6 +192,7 @@ struct TranPhases {
         c.W[(size_t)e * K + k] = v;
       }
     }
+    SPICEY_NOUNROLL
     for (int r = tid; r < P.n; r += T) {
       const uint32_t j0 = P.rhs_ptr[r], j1 = P.rhs_ptr[r + 1];
       for (int k = 0; k < K; k++) {
@@ -227,6 +259,7 @@ struct TranPhases {
 
   // ---- S: switch hysteresis (updateSwitchStatesFromSolution, simulateTRAN.ts:108-128) -----------
   SPICEY_HD void s_switches(int tid) const {
+    SPICEY_NOUNROLL
     for (int i = tid; i < P.nS; i += T)
       for (int k = 0; k < K; k++) {
         const size_t in = (size_t)c.inst[k];
@@ -249,8 +282,10 @@ struct TranPhases {
     const int oD = P.nC + P.nL + P.nV;
     for (int k = 0; k < K; k++) {
       const size_t in = (size_t)c.inst[k];
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nS; i += T)
         c.gd[(size_t)i * K + k] = spicey_switch_g(c.ison[(size_t)i * K + k], R.S_ron[in * P.nS + i], R.S_roff[in * P.nS + i]);
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nD; i += T) {
         double g, q;
         spicey_diode(volt(P.D_a[i], k) - volt(P.D_b[i], k), R.D_is[in * P.nD + i], R.D_n[in * P.nD + i], g, q);
@@ -270,18 +305,22 @@ struct TranPhases {
       if (!c.valid[k]) continue;
       const size_t in = (size_t)c.inst[k];
       double *ov = R.out_v + (in * (size_t)(R.steps + 1) + (size_t)step) * P.nOut;
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nOut; i += T) ov[i] = volt(P.out_x[i], k);
       const bool cur = R.out_i != nullptr;
       double *oi = cur ? R.out_i + (in * (size_t)(R.steps + 1) + (size_t)step) * P.nCur : nullptr;
       const double *g = R.gstat + in * P.nGstat;
       if (cur)
+        SPICEY_NOUNROLL
         for (int i = tid; i < P.nR; i += T) oi[cR + i] = (volt(P.R_a[i], k) - volt(P.R_b[i], k)) * g[i];
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nC; i += T) {
         const double dv = volt(P.C_a[i], k) - volt(P.C_b[i], k);
         if (cur) oi[cC + i] = g[P.nR + i] * (dv - c.u[(size_t)i * K + k]);
         c.u[(size_t)i * K + k] = dv;
         if (last) R.C_vprev[in * P.nC + i] = dv;
       }
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nL; i += T) {
         const double dv = volt(P.L_a[i], k) - volt(P.L_b[i], k);
         const double il = g[P.nR + P.nC + i] * dv + c.u[(size_t)(oL + i) * K + k];
@@ -289,10 +328,12 @@ struct TranPhases {
         c.u[(size_t)(oL + i) * K + k] = il;
         if (last) R.L_iprev[in * P.nL + i] = il;
       }
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nV; i += T) {
         if (cur) oi[cV + i] = c.W[(size_t)P.V_x[i] * K + k];
         if (!last) c.u[(size_t)(oV + i) * K + k] = R.src[(size_t)(step + 1) * P.nV + i];
       }
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nS; i += T) {
         const int on = c.ison[(size_t)i * K + k];
         const double gs = spicey_switch_g(on, R.S_ron[in * P.nS + i], R.S_roff[in * P.nS + i]);
@@ -300,6 +341,7 @@ struct TranPhases {
         c.gd[(size_t)i * K + k] = gs;
         if (last) R.S_ison[in * P.nS + i] = on;
       }
+      SPICEY_NOUNROLL
       for (int i = tid; i < P.nD; i += T) {
         const double vd = volt(P.D_a[i], k) - volt(P.D_b[i], k);
         const double is = R.D_is[in * P.nD + i], nn = R.D_n[in * P.nD + i];
@@ -315,17 +357,174 @@ struct TranPhases {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// v2: register-resident program.  The factor / backward task lists are step-invariant, so every
+// thread keeps its share as RMAX 16-byte records in VGPRs for the whole transient (the register file,
+// 512 KB per CU, is the largest low-latency store of the chip); only phases that do not fit are
+// streamed from L2.  Each (wave, slot) chunk belongs to one phase, so dispatch is wave-uniform.
+template <int RMAX>
+struct ResRegs {
+  uint32_t w[RMAX][4];
+  int32_t ph[RMAX];
+};
+
+template <int K, bool KTASK>
+SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+  const uint32_t meta = w0 >> 16;
+  if (!(meta & (SPICEY_R16_VALID << 8))) return;
+  const uint32_t tgt = w0 & 0xffffu, cnt = meta & 0xffu;
+  double acc[K];
+  for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)tgt * K + k];
+  if (KTASK) {
+    const uint32_t d = w1 & 0xffffu;
+    if (cnt <= 2) {
+      if (cnt >= 1) {
+        const uint32_t u0 = w1 >> 16, x0 = w2 & 0xffffu;
+        for (int k = 0; k < K; k++) acc[k] -= c.W[(size_t)u0 * K + k] * c.W[(size_t)x0 * K + k];
+      }
+      if (cnt == 2) {
+        const uint32_t u1 = w2 >> 16, x1 = w3 & 0xffffu;
+        for (int k = 0; k < K; k++) acc[k] -= c.W[(size_t)u1 * K + k] * c.W[(size_t)x1 * K + k];
+      }
+    } else {
+      const uint16_t *o = ovf + w3;
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t u = o[2 * j], x = o[2 * j + 1];
+        for (int k = 0; k < K; k++) acc[k] -= c.W[(size_t)u * K + k] * c.W[(size_t)x * K + k];
+      }
+    }
+    for (int k = 0; k < K; k++) c.W[(size_t)tgt * K + k] = acc[k] * c.W[(size_t)d * K + k];
+  } else {
+    if (cnt <= 2) {
+      if (cnt >= 1) {
+        const uint32_t l0 = w1 & 0xffffu, d0 = w1 >> 16, u0 = w2 & 0xffffu;
+        for (int k = 0; k < K; k++) acc[k] -= (c.W[(size_t)l0 * K + k] * c.W[(size_t)d0 * K + k]) * c.W[(size_t)u0 * K + k];
+      }
+      if (cnt == 2) {
+        const uint32_t l1 = w2 >> 16, d1 = w3 & 0xffffu, u1 = w3 >> 16;
+        for (int k = 0; k < K; k++) acc[k] -= (c.W[(size_t)l1 * K + k] * c.W[(size_t)d1 * K + k]) * c.W[(size_t)u1 * K + k];
+      }
+    } else {
+      const uint16_t *o = ovf + w3;
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t l = o[3 * j], d = o[3 * j + 1], u = o[3 * j + 2];
+        for (int k = 0; k < K; k++) acc[k] -= (c.W[(size_t)l * K + k] * c.W[(size_t)d * K + k]) * c.W[(size_t)u * K + k];
+      }
+    }
+    if (meta & (SPICEY_R16_RECIP << 8)) {
+      for (int k = 0; k < K; k++) {
+        if (fabs(acc[k]) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
+        acc[k] = 1.0 / acc[k];
+      }
+    }
+    for (int k = 0; k < K; k++) c.W[(size_t)tgt * K + k] = acc[k];
+  }
+}
+
+template <int K, int RMAX, bool KTASK>
+SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, const WgCtx<K> &c, const ResRegs<RMAX> &rr, int tid,
+                               int T, int p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int s = 0; s < RMAX; s++)
+    if (rr.ph[s] == p) {
+      uint32_t w0 = rr.w[s][0], w1 = rr.w[s][1], w2 = rr.w[s][2], w3 = rr.w[s][3];
+      SPICEY_OPAQUE(w0); SPICEY_OPAQUE(w1); SPICEY_OPAQUE(w2); SPICEY_OPAQUE(w3);
+      spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3);
+    }
+  const uint32_t sc = Q.st_cnt[p];
+  if (sc) {
+    const uint32_t *base = P.rec16 + (size_t)Q.st_first[p] * 4;
+    for (uint32_t j = (uint32_t)tid; j < sc; j += (uint32_t)T) {
+      const uint32_t *r = base + (size_t)j * 4;
+      spicey_exec_rec16<K, KTASK>(c, P.ovf16, r[0], r[1], r[2], r[3]);
+    }
+  }
+}
+
+template <int K, int RMAX, class Exec>
+SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, WgCtx<K> &c, int wg) {
+  const int T = ex.threads();
+  TranPhases<K> ph{P, R, c, T};
+  ex.phase(SPICEY_PH_PRO, [&](int tid) {
+    if (tid == 0) { c.flags[0] = 0; c.flags[1] = 0; c.flags[2] = -1; }
+    ph.p0_gstat(tid);
+    ResRegs<RMAX> &rr = ex.template regs<RMAX>(tid);
+    for (int s = 0; s < RMAX; s++) {
+      const bool have = s < Q.rmax;
+      const uint32_t *src = Q.res + ((size_t)(have ? s : 0) * T + tid) * 4;
+      for (int w = 0; w < 4; w++) rr.w[s][w] = have ? src[w] : 0u;
+      rr.ph[s] = have ? SPICEY_UNIFORM(Q.res_phase[(size_t)(tid >> 6) * Q.rmax + s]) : -1;
+    }
+  });
+  ex.phase(SPICEY_PH_PRO, [&](int tid) { ph.p1_static(tid); });
+  ex.phase(SPICEY_PH_PRO, [&](int tid) { ph.a0_initial(tid); });
+  unsigned long long solves = 0;
+  int32_t code = 0;
+  int64_t err_step = 0;
+  int32_t err_iter = 0;
+  if (c.flags[1]) { code = 1; }
+  const int nL = P.nLevels;
+  for (int64_t step = 0; step <= R.steps && code == 0; step++) {
+    int iter = 0;
+    for (;;) {
+      ex.phase(SPICEY_PH_B, [&](int tid) { ph.b_stamp(tid); });
+      for (int p = 0; p < nL; p++) {
+        if (P.ph_cnt[p] == 0) continue;
+        ex.phase(SPICEY_PH_U0 + (p < 31 ? p : 31), [&](int tid) {
+          spicey_uk_phase<K, RMAX, false>(P, Q, c, ex.template regs<RMAX>(tid), tid, T, p);
+        });
+      }
+      for (int p = nL; p < 2 * nL; p++) {
+        const int l = 2 * nL - 1 - p;
+        ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) {
+          spicey_uk_phase<K, RMAX, true>(P, Q, c, ex.template regs<RMAX>(tid), tid, T, p);
+        });
+      }
+      if (c.flags[1]) { code = 1; err_step = step; err_iter = iter; break; }
+      if (P.nS == 0) break;
+      ex.phase(SPICEY_PH_S, [&](int tid) { ph.s_switches(tid); });
+      const int switched = c.flags[0];
+      if (!switched || iter == SPICEY_MAX_ITER - 1) break;
+      iter++;
+      ex.phase(SPICEY_PH_A, [&](int tid) { ph.a_reiterate(tid); });
+    }
+    if (code) break;
+    {
+      int nvalid = 0;
+      for (int k = 0; k < K; k++) nvalid += c.valid[k];
+      solves += (unsigned long long)(iter + 1) * (unsigned long long)nvalid;
+    }
+    ex.phase(SPICEY_PH_Z, [&](int tid) {
+      if (tid == 0 && R.iters)
+        for (int k = 0; k < K; k++)
+          if (c.valid[k]) R.iters[(size_t)c.inst[k] * (size_t)(R.steps + 1) + (size_t)step] = iter + 1;
+      ph.z_record(tid, step);
+    });
+  }
+  ex.phase(SPICEY_PH_PRO, [&](int tid) {
+    if (tid == 0) {
+      R.status[wg * 4 + 0] = code;
+      R.status[wg * 4 + 1] = c.flags[2];
+      R.status[wg * 4 + 2] = (int32_t)err_step;
+      R.status[wg * 4 + 3] = err_iter;
+      R.solves[wg] = solves;
+    }
+  });
+}
+
 // The whole run of one workgroup.  Exec supplies `phase(f)` (run f(tid) for every thread, then
 // barrier) and `threads()`.  All control flow is workgroup-uniform: flags are read after barriers.
 template <int K, class Exec>
 SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R, WgCtx<K> &c, int wg) {
   TranPhases<K> ph{P, R, c, ex.threads()};
-  ex.phase([&](int tid) {
+  ex.phase(SPICEY_PH_PRO, [&](int tid) {
     if (tid == 0) { c.flags[0] = 0; c.flags[1] = 0; c.flags[2] = -1; }
     ph.p0_gstat(tid);
   });
-  ex.phase([&](int tid) { ph.p1_static(tid); });
-  ex.phase([&](int tid) { ph.a0_initial(tid); });
+  ex.phase(SPICEY_PH_PRO, [&](int tid) { ph.p1_static(tid); });
+  ex.phase(SPICEY_PH_PRO, [&](int tid) { ph.a0_initial(tid); });
   unsigned long long solves = 0;
   int32_t code = 0;
   int64_t err_step = 0;
@@ -334,19 +533,19 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
   for (int64_t step = 0; step <= R.steps && code == 0; step++) {
     int iter = 0;
     for (;;) {
-      ex.phase([&](int tid) { ph.b_stamp(tid); });
+      ex.phase(SPICEY_PH_B, [&](int tid) { ph.b_stamp(tid); });
       for (int l = 0; l < P.nLevels; l++) {
         if (P.lvl_slice[l] == P.lvl_slice[l + 1]) continue;
-        ex.phase([&](int tid) { ph.u_level(tid, l); });
+        ex.phase(SPICEY_PH_U0 + (l < 31 ? l : 31), [&](int tid) { ph.u_level(tid, l); });
       }
-      for (int l = P.nLevels - 1; l >= 0; l--) ex.phase([&](int tid) { ph.k_level(tid, l); });
+      for (int l = P.nLevels - 1; l >= 0; l--) ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) { ph.k_level(tid, l); });
       if (c.flags[1]) { code = 1; err_step = step; err_iter = iter; break; }
       if (P.nS == 0) break;
-      ex.phase([&](int tid) { ph.s_switches(tid); });
+      ex.phase(SPICEY_PH_S, [&](int tid) { ph.s_switches(tid); });
       const int switched = c.flags[0];
       if (!switched || iter == SPICEY_MAX_ITER - 1) break;
       iter++;
-      ex.phase([&](int tid) { ph.a_reiterate(tid); });  // b_stamp (next) resets flags[0] after this barrier
+      ex.phase(SPICEY_PH_A, [&](int tid) { ph.a_reiterate(tid); });  // b_stamp (next) resets flags[0] after this barrier
     }
     if (code) break;
     {
@@ -354,14 +553,14 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
       for (int k = 0; k < K; k++) nvalid += c.valid[k];
       solves += (unsigned long long)(iter + 1) * (unsigned long long)nvalid;
     }
-    ex.phase([&](int tid) {
+    ex.phase(SPICEY_PH_Z, [&](int tid) {
       if (tid == 0 && R.iters)
         for (int k = 0; k < K; k++)
           if (c.valid[k]) R.iters[(size_t)c.inst[k] * (size_t)(R.steps + 1) + (size_t)step] = iter + 1;
       ph.z_record(tid, step);
     });
   }
-  ex.phase([&](int tid) {
+  ex.phase(SPICEY_PH_PRO, [&](int tid) {
     if (tid == 0) {
       R.status[wg * 4 + 0] = code;
       R.status[wg * 4 + 1] = c.flags[2];

@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, "libspicey_hip.so")
 _LIB = None
 
 EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "spicey_get_state", "spicey_last_solve_count",
-           "spicey_last_kernel_ms", "spicey_get_info", "spicey_last_error", "spicey_destroy", "spicey_version"]
+           "spicey_last_kernel_ms", "spicey_get_info", "spicey_last_error", "spicey_destroy", "spicey_version",
+           "spicey_debug_phase_cycles"]
 
 
 class SpiceyNativeError(RuntimeError):
@@ -56,6 +57,8 @@ def load():
     L.spicey_destroy.restype = None
     L.spicey_destroy.argtypes = [vp]
     L.spicey_version.restype = C.c_char_p
+    L.spicey_debug_phase_cycles.restype = C.c_int32
+    L.spicey_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32]
     _LIB = L
     return L
 
@@ -68,11 +71,13 @@ class Handle:
     """Owns one SpiceyHandle (one topology, n_inst instances, one device)."""
 
     def __init__(self, flat: abi.FlatCircuit, device: int = 0, threads: int = 0, inst_per_wg: int = 0,
-                 force_global: bool = False):
+                 force_global: bool = False, profile: bool = False, interpreter: int = 0):
         self.L = load()
         self.flat = flat
         opt = abi.SpiceyOptions()
         opt.device, opt.threads, opt.inst_per_wg, opt.want_currents, opt.force_global = device, threads, inst_per_wg, 1, int(force_global)
+        opt.profile = int(profile)
+        opt.interpreter = int(interpreter)
         d = flat.desc()
         hp = C.c_void_p()
         rc = self.L.spicey_create(C.byref(d), C.byref(opt), C.byref(hp))
@@ -122,6 +127,13 @@ class Handle:
     def kernel_ms(self) -> float:
         return self.L.spicey_last_kernel_ms(self.h)
 
+    def phase_cycles(self) -> dict:
+        """Shader-clock cycles per phase kind of workgroup 0 in the last run (needs profile=True)."""
+        buf = (C.c_uint64 * 72)()
+        self.L.spicey_debug_phase_cycles(self.h, buf, 72)
+        a = list(buf)
+        return {"prologue": a[0], "B": a[1], "S": a[2], "A": a[3], "Z": a[4], "U": a[8:40], "K": a[40:72]}
+
     def state(self) -> dict:
         f = self.flat
         st = {"C_vprev": np.zeros((f.n_inst, f.nC)), "L_iprev": np.zeros((f.n_inst, f.nL)), "D_vdprev": np.zeros((f.n_inst, f.nD)),
@@ -147,8 +159,8 @@ class Handle:
 class HipBackend:
     """Backend interface used by spicey_amd.simulate: one handle per call (the reference API is stateless)."""
 
-    def __init__(self, device: int = 0, threads: int = 0, inst_per_wg: int = 0, force_global: bool = False):
-        self.kw = dict(device=device, threads=threads, inst_per_wg=inst_per_wg, force_global=force_global)
+    def __init__(self, device: int = 0, threads: int = 0, inst_per_wg: int = 0, force_global: bool = False, interpreter: int = 0):
+        self.kw = dict(device=device, threads=threads, inst_per_wg=inst_per_wg, force_global=force_global, interpreter=interpreter)
         self.info: Optional[dict] = None
 
     def run(self, flat: abi.FlatCircuit, steps: int, dt: float, src: np.ndarray, want_currents: bool = True,

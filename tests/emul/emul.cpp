@@ -18,9 +18,15 @@ namespace {
 struct SeqExec {
   int T;
   bool reverse;
+  std::vector<ResRegs<16>> *rr = nullptr;  // per-thread "registers" of the v2 interpreter
   int threads() const { return T; }
+  template <int RMAX>
+  ResRegs<RMAX> &regs(int tid) {
+    static_assert(RMAX == 16, "emulator instantiates RMAX = 16");
+    return (*rr)[tid];
+  }
   template <class F>
-  void phase(F f) {
+  void phase(int, F f) {
     if (!reverse)
       for (int t = 0; t < T; t++) f(t);
     else
@@ -29,7 +35,7 @@ struct SeqExec {
 };
 
 template <int K>
-void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T, bool reverse) {
+void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T, bool reverse, int rmax) {
   const int ngroups = (R.n_inst + K - 1) / K;
   std::vector<double> W((size_t)P.nW * K), u((size_t)(P.nU + 1) * K), gd((size_t)(P.nGdyn + 1) * K);
   std::vector<int32_t> ison((size_t)(P.nS + 1) * K), flags(4);
@@ -42,16 +48,24 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
       c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
     }
     SeqExec ex{T, reverse};
-    spicey_tran_run<K>(ex, P, R, c, g);
+    if (rmax < 0) {
+      spicey_tran_run<K>(ex, P, R, c, g);
+    } else {
+      HostResident hr;
+      spicey_build_resident(hp, T, rmax, hr);
+      SpiceyResident Q = hr.bind(hr.blob.data());
+      std::vector<ResRegs<16>> regs(T);
+      ex.rr = &regs;
+      spicey_tran_run_v2<K, 16>(ex, P, Q, R, c, g);
+    }
   }
-  (void)hp;
 }
 }  // namespace
 
 extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, int64_t steps, double dt, const double *src,
                                    double *out_v, double *out_i, int32_t *iters, double *C_vprev, double *L_iprev,
                                    double *D_vdprev, int32_t *S_ison, int32_t reverse, SpiceyInfo *info, int32_t *err4,
-                                   int64_t *solves_out) {
+                                   int64_t *solves_out, int32_t rmax /* <0: v1 interpreter, else v2 with rmax resident slots */) {
   HostProgram hp;
   std::string err;
   int32_t rc = spicey_build_program(d, hp, err);
@@ -84,10 +98,11 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
   std::vector<unsigned long long> solves(ngroups);
   R.status = status.data(); R.solves = solves.data();
   if (T <= 0 || (T & 63)) return SPICEY_ERR_BAD_DESC;
+  if (rmax > 16 || (rmax >= 0 && !P.has16)) return SPICEY_ERR_BAD_DESC;
   switch (K) {
-    case 1: run_groups<1>(hp, P, R, T, reverse != 0); break;
-    case 2: run_groups<2>(hp, P, R, T, reverse != 0); break;
-    case 4: run_groups<4>(hp, P, R, T, reverse != 0); break;
+    case 1: run_groups<1>(hp, P, R, T, reverse != 0, rmax); break;
+    case 2: run_groups<2>(hp, P, R, T, reverse != 0, rmax); break;
+    case 4: run_groups<4>(hp, P, R, T, reverse != 0, rmax); break;
     default: return SPICEY_ERR_BAD_DESC;
   }
   int64_t tot = 0;

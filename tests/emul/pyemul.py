@@ -21,7 +21,7 @@ def lib():
         f64p, i32p, i64p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
         L.spicey_emul_run.restype = C.c_int32
         L.spicey_emul_run.argtypes = [C.POINTER(abi.SpiceyDesc), C.c_int32, C.c_int32, C.c_int64, C.c_double, f64p, f64p, f64p,
-                                      i32p, f64p, f64p, f64p, i32p, C.c_int32, C.POINTER(abi.SpiceyInfo), i32p, i64p]
+                                      i32p, f64p, f64p, f64p, i32p, C.c_int32, C.POINTER(abi.SpiceyInfo), i32p, i64p, C.c_int32]
         L.spicey_emul_symbolic.restype = C.c_int32
         L.spicey_emul_symbolic.argtypes = [C.POINTER(abi.SpiceyDesc), i32p, i32p, i32p, C.POINTER(abi.SpiceyInfo), i64p]
         _LIB = L
@@ -33,8 +33,9 @@ def _p(a, t):
 
 
 class EmulBackend:
-    def __init__(self, K=1, T=256, reverse=False):
-        self.K, self.T, self.reverse = K, T, reverse
+    def __init__(self, K=1, T=256, reverse=False, rmax=-1):
+        """rmax < 0: v1 interpreter (sliced-ELL, 32-bit); rmax >= 0: v2 with `rmax` register-resident slots."""
+        self.K, self.T, self.reverse, self.rmax = K, T, reverse, rmax
         self.info = None
         self.solves = None
 
@@ -55,7 +56,7 @@ class EmulBackend:
         rc = L.spicey_emul_run(C.byref(d), self.K, self.T, steps, dt, _p(src, C.c_double), _p(out_v, C.c_double),
                                _p(out_i, C.c_double), _p(iters, C.c_int32), _p(st["C_vprev"], C.c_double),
                                _p(st["L_iprev"], C.c_double), _p(st["D_vdprev"], C.c_double), _p(st["S_ison"], C.c_int32),
-                               1 if self.reverse else 0, C.byref(info), _p(err4, C.c_int32), C.byref(solves))
+                               1 if self.reverse else 0, C.byref(info), _p(err4, C.c_int32), C.byref(solves), self.rmax)
         self.info = info.as_dict()
         self.solves = solves.value
         detail = f"singular at inst {err4[1]} step {err4[2]} iter {err4[3]}" if rc == abi.ERR_SINGULAR else ""

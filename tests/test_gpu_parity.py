@@ -21,13 +21,15 @@ RTOL, ATOL = 1e-9, 1e-12
 # test_bridge_rectifier_reference_is_ill_conditioned), so 1e-9 parity is not defined there for ANY
 # elimination order; bridge_bleed is the same circuit made well-posed and is held to 1e-9.
 LOOSE = {"bridge_rectifier": 1e-4}
+LOOSE_ATOL = 1e-3  # volts / amperes, only for the ill-conditioned netlists above
 
 
 def tol_ratio(got, ref, rtol=RTOL):
     ref = np.asarray(ref, dtype=np.float64)
     got = np.asarray(got, dtype=np.float64)
+    atol = ATOL if rtol == RTOL else LOOSE_ATOL
     with np.errstate(invalid="ignore"):
-        r = np.abs(got - ref) / (rtol * np.abs(ref) + ATOL)
+        r = np.abs(got - ref) / (rtol * np.abs(ref) + atol)
     same_nonfinite = (~np.isfinite(ref)) & ((got == ref) | (np.isnan(got) & np.isnan(ref)))
     r = np.where(same_nonfinite, 0.0, r)
     r = np.nan_to_num(r, nan=np.inf)
@@ -101,8 +103,10 @@ def test_public_api_default_backend():
     assert tol_ratio(tran2["nodeVoltages"]["2"], farr(g["runs"][1]["V"]["2"])).max() <= 1.0
 
 
-@pytest.mark.parametrize("K,T,force_global", [(1, 64, False), (1, 1024, False), (2, 256, False), (4, 256, False), (1, 256, True), (2, 512, True)])
-def test_geometry_variants_batched(K, T, force_global, oracle_backend):
+@pytest.mark.parametrize("K,T,force_global,interp", [(1, 64, False, 1), (1, 1024, False, 1), (2, 256, False, 1), (4, 256, False, 1),
+                                                     (1, 256, True, 1), (2, 512, True, 1), (1, 64, False, 2), (1, 1024, False, 2),
+                                                     (2, 512, False, 2), (2, 1024, False, 2)])
+def test_geometry_variants_batched(K, T, force_global, interp, oracle_backend):
     """Instance batches (config 4 shape, small): every (instances/workgroup, threads, LDS|global) variant."""
     from spicey_amd.lib import HipBackend
     flats = []
@@ -112,10 +116,11 @@ def test_geometry_variants_batched(K, T, force_global, oracle_backend):
     batch = abi.stack_instances(flats)
     dt, steps = abi.computeEffectiveTimeStep(1e-6, 3e-5)
     src = abi.source_table(ckt, dt, steps)
-    be = HipBackend(threads=T, inst_per_wg=K, force_global=force_global)
+    be = HipBackend(threads=T, inst_per_wg=K, force_global=force_global, interpreter=interp)
     got = be.run(batch, steps, dt, src)
     assert got["status"] == 0, got["detail"]
     assert be.info["inst_per_wg"] == K and be.info["threads"] == T and (be.info["lds_bytes"] == 0) == force_global
+    assert be.info["interpreter"] == interp
     ref = oracle_backend.run(batch, steps, dt, src)
     assert tol_ratio(got["out_v"], ref["out_v"]).max() <= 1.0
     assert tol_ratio(got["out_i"], ref["out_i"]).max() <= 1.0

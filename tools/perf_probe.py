@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--currents", type=int, default=1)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--global", dest="force_global", type=int, default=0)
+    ap.add_argument("--profile", type=int, default=0)
+    ap.add_argument("--interp", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for cfg in args.configs.split(","):
@@ -33,7 +35,7 @@ def main():
         ckt = parseNetlist(getattr(synth, args.workload)(args.n, seed=1, tran=".tran 1e-6 1e-2"))
         steps = args.steps
         src = torch.tensor(abi.source_table(ckt, 1e-6, steps), device=dev)
-        h = Handle(flat, threads=T, inst_per_wg=K, force_global=bool(args.force_global))
+        h = Handle(flat, threads=T, inst_per_wg=K, force_global=bool(args.force_global), profile=bool(args.profile), interpreter=args.interp)
         info = h.info()
         out_v = torch.empty((B, steps + 1, info["n_out"]), dtype=torch.float64, device=dev)
         out_i = torch.empty((B, steps + 1, info["n_cur"]), dtype=torch.float64, device=dev) if args.currents else None
@@ -48,10 +50,15 @@ def main():
             ms = h.kernel_ms()
             best = ms if best is None else min(best, ms)
         solves = h.solves()
-        rec = dict(workload=args.workload, n=args.n, B=B, K=info["inst_per_wg"], T=info["threads"], lds=info["lds_bytes"],
+        rec = dict(interp=info['interpreter'], rslots=info['resident_slots'], rtasks=info['resident_tasks'], stasks=info['streamed_tasks'], workload=args.workload, n=args.n, B=B, K=info["inst_per_wg"], T=info["threads"], lds=info["lds_bytes"],
                    steps=steps, kernel_ms=best, solves=solves, solves_per_s=solves / (best * 1e-3), wall_ms=(t1 - t0) * 1e3,
                    us_per_step=best * 1e3 / (steps + 1), levels=info["n_levels"], nnz_lu=info["nnz_lu"], currents=args.currents,
                    finite=bool(torch.isfinite(out_v[:, -1]).all().item()))
+        if args.profile:
+            pc = h.phase_cycles()
+            per = lambda v: round(v / (steps + 1))  # noqa: E731
+            rec['cyc_per_step'] = dict(B=per(pc['B']), Z=per(pc['Z']), U=[per(x) for x in pc['U'][:info['n_levels']]],
+                                       K=[per(x) for x in pc['K'][:info['n_levels']]], total=per(pc['B'] + pc['Z'] + sum(pc['U']) + sum(pc['K'])))
         print(json.dumps(rec), flush=True)
         h.close()
         del out_v, out_i
