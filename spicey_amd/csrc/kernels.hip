@@ -23,7 +23,11 @@ struct GpuExec {
   __device__ __forceinline__ void phase(int tag, F f) {
     long long t0 = 0;
     if (prof && threadIdx.x == 0) t0 = clock64();
-    f((int)threadIdx.x);
+    // The thread id is made opaque per phase: otherwise hipcc hoists every `base + tid * 8` address (a VGPR
+    // pair per array and instance) out of the time loop and the register-resident program spills.
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    f(tid);
     __syncthreads();
     if (prof && threadIdx.x == 0) prof[tag] += (unsigned long long)(clock64() - t0);
   }
@@ -60,27 +64,30 @@ __global__ void __launch_bounds__(1024) spicey_tran_kernel(SpiceyProg P, SpiceyR
 }
 
 // v2: register-resident program (LDS workspace only; 16-bit records)
-template <int RMAX>
+template <class Regs>
 struct GpuExecV2 {
   unsigned long long *prof;
-  ResRegs<RMAX> rr;
+  Regs rr;
   __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
-  template <int R2>
-  __device__ __forceinline__ ResRegs<R2> &regs(int) {
-    static_assert(R2 == RMAX, "resident slot count mismatch");
+  template <class R2>
+  __device__ __forceinline__ R2 &regs(int) {
     return rr;
   }
   template <class F>
   __device__ __forceinline__ void phase(int tag, F f) {
     long long t0 = 0;
     if (prof && threadIdx.x == 0) t0 = clock64();
-    f((int)threadIdx.x);
+    // The thread id is made opaque per phase: otherwise hipcc hoists every `base + tid * 8` address (a VGPR
+    // pair per array and instance) out of the time loop and the register-resident program spills.
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    f(tid);
     __syncthreads();
     if (prof && threadIdx.x == 0) prof[tag] += (unsigned long long)(clock64() - t0);
   }
 };
 
-template <int K, int RMAX, int MAXT>
+template <int K, int RMAX, int NSV, int MAXT>
 __global__ void __launch_bounds__(MAXT) spicey_tran_kernel_v2(SpiceyProg P, SpiceyResident Q, SpiceyRun R) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WgCtx<K> c;
@@ -97,14 +104,14 @@ __global__ void __launch_bounds__(MAXT) spicey_tran_kernel_v2(SpiceyProg P, Spic
     c.valid[k] = in < R.n_inst;
     c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
   }
-  GpuExecV2<RMAX> ex;
+  GpuExecV2<ResRegs<K, RMAX, NSV>> ex;
   ex.prof = R.prof ? R.prof + (size_t)wg * SPICEY_PH_SLOTS : nullptr;
-  spicey_tran_run_v2<K, RMAX>(ex, P, Q, R, c, wg);
+  spicey_tran_run_v2<K, RMAX, NSV>(ex, P, Q, R, c, wg);
 }
 
-template <int K, int RMAX, int MAXT>
+template <int K, int RMAX, int NSV, int MAXT>
 hipError_t launch_v2_t(const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, int grid, int threads, size_t lds, hipStream_t st) {
-  auto kern = spicey_tran_kernel_v2<K, RMAX, MAXT>;
+  auto kern = spicey_tran_kernel_v2<K, RMAX, NSV, MAXT>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -161,13 +168,13 @@ hipError_t spicey_launch_tran_v2(const SpiceyProg &P, const SpiceyResident &Q, c
   const size_t bytes = spicey_lds_bytes(P, K, true);
   if (threads <= 512) {
     switch (K) {
-      case 1: return launch_v2_t<1, 16, 512>(P, Q, R, grid, threads, bytes, st);
-      case 2: return launch_v2_t<2, 16, 512>(P, Q, R, grid, threads, bytes, st);
+      case 1: return launch_v2_t<1, 16, 8, 512>(P, Q, R, grid, threads, bytes, st);
+      case 2: return launch_v2_t<2, 16, 8, 512>(P, Q, R, grid, threads, bytes, st);
     }
   } else {
     switch (K) {
-      case 1: return launch_v2_t<1, 8, 1024>(P, Q, R, grid, threads, bytes, st);
-      case 2: return launch_v2_t<2, 8, 1024>(P, Q, R, grid, threads, bytes, st);
+      case 1: return launch_v2_t<1, 8, 4, 1024>(P, Q, R, grid, threads, bytes, st);
+      case 2: return launch_v2_t<2, 8, 4, 1024>(P, Q, R, grid, threads, bytes, st);
     }
   }
   return hipErrorInvalidValue;

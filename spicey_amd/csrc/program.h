@@ -38,6 +38,7 @@ struct SpiceySlice {
 struct SpiceyProg {
   int32_t n;       // unknowns = n_nodes + nV
   int32_t nLU;     // entries of L+U
+  int32_t nRestore; // entries [0, nRestore) are dynamic or update targets and are re-stamped every step; the rest never change
   int32_t nW;      // nLU + n
   int32_t nLevels; // etree height
   int32_t nR, nC, nL, nV, nS, nD;
@@ -85,6 +86,21 @@ struct SpiceyProg {
   // w0 = tgt | meta<<16, meta = cnt (8 bits) | flags<<8 (SPICEY_R16_*).
   //   U, cnt<=2: w1 = l0|d0<<16, w2 = u0|l1<<16, w3 = d1|u1<<16 ; cnt>2: w3 = offset of cnt triplets in ovf16
   //   K        : w1 = d|u0<<16,  w2 = x0|u1<<16, w3 = x1        ; cnt>2: w3 = offset of cnt pairs in ovf16
+  // Per-entry dynamic-stamp descriptor (v2 B phase): bits 0-13 idx0+1, bit 14 sign0, bits 15-28 idx1+1,
+  // bit 29 sign1 (gdyn indices; 0 = none), bit 30 leaf diagonal (store reciprocal), bit 31 overflow: the
+  // entry has > 2 dynamic stamps or an index > 16382 and is handled through dynx_* instead.
+  const uint32_t *ent_dd;    // [nLU]
+  const uint32_t *dynx_ent;  // [nDynX] entry | SPICEY_TGT_RECIP
+  const uint32_t *dynx_ptr;  // [nDynX+1]
+  const uint32_t *dynx_idx;  // gdyn index | sign
+  int32_t nDynX;
+  // Per-row right-hand-side descriptor (v2): four 16-bit fields (u index + 1) | sign << 15, 0 = none;
+  // row_desc[r][1] == 0xFFFFFFFF: more than 4 contributions, row listed in rowx and summed from rhs_ptr/rhs_idx
+  const uint32_t *row_desc;  // [n][2]
+  const uint32_t *rowx;      // [nRowX]
+  int32_t nRowX;
+  // element terminals packed a | b << 16 as W indices, 0xFFFF = ground
+  const uint32_t *R_ab, *C_ab, *L_ab, *D_ab;
   const uint32_t *rec16;     // [nRec16][4]
   const uint16_t *ovf16;
   const uint32_t *ph_first;  // [2 nLevels]
@@ -128,6 +144,7 @@ struct SpiceyRun {
   double *gstat;  // [n_inst][nGstat]
   double *statv;  // [n_inst][nLU]  static part of every entry (pre-inverted for static leaf diagonals)
   double *rcoef;  // [n_inst][nRhsIdx] coefficient of every right-hand-side contribution
+  double *dpar;   // [n_inst][nD][2] per-diode {1/(N VT), Is/(N VT)}
   // global-memory fallback for W/u/gdyn when LDS is too small: [n_workgroups][...]
   double *gW;
   // io

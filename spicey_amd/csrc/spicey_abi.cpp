@@ -33,7 +33,7 @@ struct SpiceyHandle {
          *d_Dis = nullptr, *d_Dn = nullptr;
   double *d_Cv = nullptr, *d_Li = nullptr, *d_Dv = nullptr;
   int32_t *d_Son = nullptr;
-  double *d_gstat = nullptr, *d_statv = nullptr, *d_rcoef = nullptr, *d_gW = nullptr;
+  double *d_gstat = nullptr, *d_statv = nullptr, *d_rcoef = nullptr, *d_gW = nullptr, *d_dpar = nullptr;
   int32_t *d_status = nullptr;
   unsigned long long *d_solves = nullptr;
   unsigned long long *d_prof = nullptr;
@@ -75,7 +75,7 @@ extern "C" void spicey_destroy(SpiceyHandle *h) {
   if (!h) return;
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
   void *ptrs[] = {h->d_res, h->d_blob, h->d_R, h->d_C, h->d_L, h->d_Sron, h->d_Sroff, h->d_Svon, h->d_Svoff, h->d_Dis, h->d_Dn, h->d_Cv,
-                  h->d_Li, h->d_Dv, h->d_Son, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_status, h->d_solves, h->d_prof};
+                  h->d_Li, h->d_Dv, h->d_Son, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_status, h->d_solves, h->d_prof};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -195,6 +195,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   if ((rc = upload(h, &h->d_gstat, nodbl, ni * P.nGstat)) != SPICEY_OK) return fail(rc);
   if ((rc = upload(h, &h->d_statv, nodbl, ni * P.nLU)) != SPICEY_OK) return fail(rc);
   if ((rc = upload(h, &h->d_rcoef, nodbl, ni * (size_t)(P.nRhsIdx + 1))) != SPICEY_OK) return fail(rc);
+  if ((rc = upload(h, &h->d_dpar, nodbl, ni * (size_t)P.nD * 2)) != SPICEY_OK) return fail(rc);
   if (!h->lds)
     if ((rc = upload(h, &h->d_gW, nodbl, (size_t)h->grid * spicey_gw_doubles_per_wg(P, K))) != SPICEY_OK) return fail(rc);
   const int32_t *noint = nullptr;
@@ -252,7 +253,7 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   R.S_ron = h->d_Sron; R.S_roff = h->d_Sroff; R.S_von = h->d_Svon; R.S_voff = h->d_Svoff;
   R.D_is = h->d_Dis; R.D_n = h->d_Dn;
   R.C_vprev = h->d_Cv; R.L_iprev = h->d_Li; R.D_vdprev = h->d_Dv; R.S_ison = h->d_Son;
-  R.gstat = h->d_gstat; R.statv = h->d_statv; R.rcoef = h->d_rcoef; R.gW = h->d_gW;
+  R.gstat = h->d_gstat; R.statv = h->d_statv; R.rcoef = h->d_rcoef; R.gW = h->d_gW; R.dpar = h->d_dpar;
   R.src = d_src_table; R.out_v = d_out_v; R.out_i = d_out_i; R.iters = d_iters;
   R.status = h->d_status; R.solves = h->d_solves; R.prof = h->d_prof;
   if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, (size_t)h->grid * 72 * sizeof(unsigned long long), st));

@@ -257,12 +257,18 @@ struct NDOrder {
 };
 
 struct EntryIndex {
-  // CSR of the permuted L+U pattern
-  std::vector<int> ptr, col;
-  int find(int r, int c) const {
+  // CSR of the permuted L+U pattern.  Entry IDS (the W indices the device uses) are a renumbering of the
+  // CSR positions by class: [dynamic | static update targets | static never-modified], so that only the first
+  // two classes have to be re-stamped every step and the dynamic ones are contiguous (wave-uniform paths).
+  std::vector<int> ptr, col, id_of_pos, row_of_id, col_of_id;
+  int pos(int r, int c) const {
     auto b = col.begin() + ptr[r], e = col.begin() + ptr[r + 1];
     auto it = std::lower_bound(b, e, c);
     return (it != e && *it == c) ? (int)(it - col.begin()) : -1;
+  }
+  int find(int r, int c) const {
+    const int p = pos(r, c);
+    return p < 0 ? -1 : id_of_pos[p];
   }
 };
 
@@ -467,6 +473,37 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
   }
   const int nLU = E.ptr[n];
   hp.hdr.nLU = nLU; hp.hdr.nW = nLU + n; hp.hdr.nLevels = nLevels;
+  {
+    // classes of the CSR positions
+    std::vector<uint8_t> is_dyn(nLU, 0), is_tgt(nLU, 0);
+    auto mark2 = [&](const int32_t *a, const int32_t *b, int cnt) {
+      for (int i = 0; i < cnt; i++) {
+        const int i1 = a[i] - 1, i2 = b[i] - 1;
+        auto m = [&](int r, int c) { const int p = E.pos(hp.rpos[r], hp.cpos[c]); if (p >= 0) is_dyn[p] = 1; };
+        if (i1 >= 0) m(i1, i1);
+        if (i2 >= 0) m(i2, i2);
+        if (i1 >= 0 && i2 >= 0) { m(i1, i2); m(i2, i1); }
+      }
+    };
+    mark2(d->S_n1, d->S_n2, nS);
+    mark2(d->D_np, d->D_nm, nD);
+    for (int k = 0; k < n; k++)
+      for (int a : upper[k])
+        for (int b : upper[k]) is_tgt[E.pos(a, b)] = 1;
+    E.id_of_pos.assign(nLU, -1);
+    int next = 0;
+    for (int cls = 0; cls < 3; cls++)
+      for (int p = 0; p < nLU; p++) {
+        const int c = is_dyn[p] ? 0 : (is_tgt[p] ? 1 : 2);
+        if (c == cls) E.id_of_pos[p] = next++;
+      }
+    int nrest = 0;
+    for (int p = 0; p < nLU; p++) nrest += (is_dyn[p] || is_tgt[p]) ? 1 : 0;
+    hp.hdr.nRestore = nrest;
+    E.row_of_id.assign(nLU, 0); E.col_of_id.assign(nLU, 0);
+    for (int r = 0; r < n; r++)
+      for (int p = E.ptr[r]; p < E.ptr[r + 1]; p++) { E.row_of_id[E.id_of_pos[p]] = r; E.col_of_id[E.id_of_pos[p]] = E.col[p]; }
+  }
   std::vector<int> diag(n);
   for (int k = 0; k < n; k++) diag[k] = E.find(k, k);
 
@@ -579,8 +616,8 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
       uint32_t t = prods[i].tgt;
       if ((int)t < nLU) {
         // diagonal that becomes final now?
-        int r = (int)(std::upper_bound(E.ptr.begin(), E.ptr.end(), (int)t) - E.ptr.begin()) - 1;
-        if (E.col[t] == r && hp.level[r] == l + 1) t |= SPICEY_TGT_RECIP;
+        const int r = E.row_of_id[t];
+        if (E.col_of_id[t] == r && hp.level[r] == l + 1) t |= SPICEY_TGT_RECIP;
       }
       tasks.emplace_back(t, std::move(flat));
       i = j;
@@ -612,7 +649,7 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
 
   // ---- 5c'. compact 16-bit records of the same tasks, phases in execution order -------------------
   hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear();
-  hp.hdr.has16 = (nLU + n) < 65536 ? 1 : 0;
+  hp.hdr.has16 = (nLU + n) < 65535 ? 1 : 0;  // 0xFFFF = ground in the packed terminal words
   if (hp.hdr.has16) {
     auto emit_u = [&](uint32_t tgt, bool recip, const std::vector<uint32_t> &tr) {  // tr = (l,d,u)*
       const uint32_t cnt = (uint32_t)(tr.size() / 3);
@@ -652,6 +689,8 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
           prods.push_back({(uint32_t)(nLU + a), le, (uint32_t)diag[k], (uint32_t)(nLU + k)});
         }
       std::stable_sort(prods.begin(), prods.end(), [](const Prod &x, const Prod &y) { return x.tgt < y.tgt; });
+      struct UT { uint32_t t; bool recip; std::vector<uint32_t> tr; };
+      std::vector<UT> uts;
       for (size_t i = 0; i < prods.size();) {
         size_t j = i;
         std::vector<uint32_t> tr;
@@ -659,18 +698,26 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
         uint32_t t = prods[i].tgt;
         bool recip = false;
         if ((int)t < nLU) {
-          int r = (int)(std::upper_bound(E.ptr.begin(), E.ptr.end(), (int)t) - E.ptr.begin()) - 1;
-          recip = E.col[t] == r && hp.level[r] == l + 1;
+          const int r = E.row_of_id[t];
+          recip = E.col_of_id[t] == r && hp.level[r] == l + 1;
         }
         if (tr.size() / 3 > 255) too_long = true;
-        emit_u(t, recip, tr);
+        uts.push_back({t, recip, std::move(tr)});
         i = j;
       }
+      // same (recip, count) next to each other: the 64-lane chunks then take one code path
+      std::stable_sort(uts.begin(), uts.end(), [](const UT &x, const UT &y) {
+        if (x.recip != y.recip) return x.recip > y.recip;
+        return x.tr.size() > y.tr.size();
+      });
+      for (auto &u : uts) emit_u(u.t, u.recip, u.tr);
       hp.ph_cnt.push_back((uint32_t)(hp.rec16.size() / 4) - hp.ph_first.back());
     }
     for (int l = nLevels - 1; l >= 0; l--) {  // backward phases, top level first
       hp.ph_first.push_back((uint32_t)(hp.rec16.size() / 4));
-      for (int k : by_level[l]) {
+      std::vector<int> ks = by_level[l];
+      std::stable_sort(ks.begin(), ks.end(), [&](int x, int y) { return upper[x].size() > upper[y].size(); });
+      for (int k : ks) {
         std::vector<uint32_t> pr;
         for (int b : upper[k]) { pr.push_back((uint32_t)E.find(k, b)); pr.push_back((uint32_t)(nLU + b)); }
         if (pr.size() / 2 > 255) too_long = true;
@@ -685,6 +732,45 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
   }
   hp.hdr.nRec16 = (int32_t)(hp.rec16.size() / 4);
 
+  // ---- 5c''. v2 B-phase descriptors: per-entry dynamic stamps, per-row right-hand side -----------
+  hp.ent_dd.assign(nLU, 0u);
+  hp.dynx_ent.clear(); hp.dynx_ptr.assign(1, 0u); hp.dynx_idx.clear();
+  for (int e = 0; e < nLU; e++) {
+    uint32_t dd = (hp.ent_flag[e] & 1) && !dyn[e].empty() ? (1u << 30) : 0u;
+    bool ovf = dyn[e].size() > 2;
+    for (uint32_t v : dyn[e]) ovf = ovf || SPICEY_IDX(v) + 1 > 0x3fffu;
+    if (ovf) {
+      dd |= 1u << 31;
+      hp.dynx_ent.push_back((uint32_t)e | ((hp.ent_flag[e] & 1) ? SPICEY_TGT_RECIP : 0u));
+      hp.dynx_idx.insert(hp.dynx_idx.end(), dyn[e].begin(), dyn[e].end());
+      hp.dynx_ptr.push_back((uint32_t)hp.dynx_idx.size());
+    } else {
+      for (size_t i = 0; i < dyn[e].size(); i++) {
+        const uint32_t f = (SPICEY_IDX(dyn[e][i]) + 1) | ((dyn[e][i] & SPICEY_NEG) ? 0x4000u : 0u);
+        dd |= f << (15 * i);
+      }
+    }
+    hp.ent_dd[e] = dd;
+  }
+  hp.hdr.nDynX = (int32_t)hp.dynx_ent.size();
+  hp.row_desc.assign((size_t)n * 2, 0u);
+  hp.rowx.clear();
+  for (int r = 0; r < n; r++) {
+    const uint32_t j0 = hp.rhs_ptr[r], j1 = hp.rhs_ptr[r + 1];
+    bool ovf = j1 - j0 > 4;
+    for (uint32_t j = j0; j < j1; j++) ovf = ovf || SPICEY_IDX(hp.rhs_idx[j]) + 1 > 0x7fffu;
+    if (ovf) {
+      hp.row_desc[(size_t)r * 2 + 1] = 0xFFFFFFFFu;
+      hp.rowx.push_back((uint32_t)r);
+    } else {
+      for (uint32_t j = j0; j < j1; j++) {
+        const uint32_t f = (SPICEY_IDX(hp.rhs_idx[j]) + 1) | ((hp.rhs_idx[j] & SPICEY_NEG) ? 0x8000u : 0u);
+        hp.row_desc[(size_t)r * 2 + (j - j0) / 2] |= f << (16 * ((j - j0) & 1));
+      }
+    }
+  }
+  hp.hdr.nRowX = (int32_t)hp.rowx.size();
+
   // ---- 5d. element terminals and outputs as W indices -------------------------------------------
   auto xpos = [&](int node) -> int32_t { return node == 0 ? -1 : (int32_t)(nLU + hp.cpos[node - 1]); };
   auto map2 = [&](const int32_t *a, const int32_t *b, int cnt, std::vector<int32_t> &oa, std::vector<int32_t> &ob) {
@@ -697,6 +783,12 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
   map2(d->S_n1, d->S_n2, nS, hp.S_a, hp.S_b);
   map2(d->S_cp, d->S_cn, nS, hp.S_cp, hp.S_cn);
   map2(d->D_np, d->D_nm, nD, hp.D_a, hp.D_b);
+  auto pack2 = [&](const std::vector<int32_t> &a, const std::vector<int32_t> &b, std::vector<uint32_t> &o) {
+    o.resize(a.size());
+    for (size_t i = 0; i < a.size(); i++)
+      o[i] = (uint32_t)(a[i] < 0 ? 0xFFFF : (a[i] & 0xFFFF)) | ((uint32_t)(b[i] < 0 ? 0xFFFF : (b[i] & 0xFFFF)) << 16);
+  };
+  pack2(hp.R_a, hp.R_b, hp.R_ab); pack2(hp.C_a, hp.C_b, hp.C_ab); pack2(hp.L_a, hp.L_b, hp.L_ab); pack2(hp.D_a, hp.D_b, hp.D_ab);
   hp.V_x.resize(nV);
   for (int k = 0; k < nV; k++) hp.V_x[k] = nLU + hp.cpos[nN + k];
   hp.out_x.resize(nOut);
@@ -741,6 +833,14 @@ void HostProgram::pack() {
   add_section(blob, offsets, ovf16);     // 35
   add_section(blob, offsets, ph_first);  // 36
   add_section(blob, offsets, ph_cnt);    // 37
+  add_section(blob, offsets, ent_dd);    // 38
+  add_section(blob, offsets, dynx_ent);  // 39
+  add_section(blob, offsets, dynx_ptr);  // 40
+  add_section(blob, offsets, dynx_idx);  // 41
+  add_section(blob, offsets, row_desc);  // 42
+  add_section(blob, offsets, rowx);      // 43
+  add_section(blob, offsets, R_ab); add_section(blob, offsets, C_ab);  // 44 45
+  add_section(blob, offsets, L_ab); add_section(blob, offsets, D_ab);  // 46 47
 }
 
 SpiceyProg HostProgram::bind(const void *base) const {
@@ -759,6 +859,8 @@ SpiceyProg HostProgram::bind(const void *base) const {
   p.S_a = i32(26); p.S_b = i32(27); p.S_cp = i32(28); p.S_cn = i32(29); p.D_a = i32(30); p.D_b = i32(31);
   p.V_x = i32(32); p.out_x = i32(33);
   p.rec16 = u32(34); p.ovf16 = (const uint16_t *)(b + offsets[35]); p.ph_first = u32(36); p.ph_cnt = u32(37);
+  p.ent_dd = u32(38); p.dynx_ent = u32(39); p.dynx_ptr = u32(40); p.dynx_idx = u32(41); p.row_desc = u32(42); p.rowx = u32(43);
+  p.R_ab = u32(44); p.C_ab = u32(45); p.L_ab = u32(46); p.D_ab = u32(47);
   return p;
 }
 

@@ -29,6 +29,7 @@ struct HostProgram {
   std::vector<SpiceySlice> bk_slice;
   std::vector<uint32_t> rec16, ph_first, ph_cnt;  // compact records (has16)
   std::vector<uint16_t> ovf16;
+  std::vector<uint32_t> ent_dd, dynx_ent, dynx_ptr, dynx_idx, row_desc, rowx, R_ab, C_ab, L_ab, D_ab;
   std::vector<int32_t> R_a, R_b, C_a, C_b, L_a, L_b, S_a, S_b, S_cp, S_cn, D_a, D_b, V_x, out_x;
 
   // Serialise all arrays into one blob (16-byte aligned sections) and return a SpiceyProg whose

@@ -34,8 +34,10 @@
 // a mask pair per record) out of the time loop and spills.
 #define SPICEY_OPAQUE(x) asm volatile("" : "+v"(x))
 #define SPICEY_NOUNROLL _Pragma("unroll 1")  // thread-strided loops run 1-2 trips: unrolling only costs VGPRs
+#define SPICEY_SCHED_FENCE __builtin_amdgcn_sched_barrier(0)  // keep the K instances' code from being interleaved
 #else
 #define SPICEY_NOUNROLL
+#define SPICEY_SCHED_FENCE
 #define SPICEY_UNIFORM(x) (x)
 #define SPICEY_OPAQUE(x) (void)(x)
 #endif
@@ -61,20 +63,43 @@ struct WgCtx {
   int32_t valid[K];
 };
 
+// 1/x for pivots: hardware reciprocal seed + two Newton steps (<= 1 ulp; the result feeds a 1e-9 parity
+// budget, and the reference's own quotient order differs anyway).  The IEEE-exact quotient hipcc emits
+// for `1.0 / x` is ~3x longer and sits on the critical path of every factor level.
+SPICEY_HD double spicey_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+
 SPICEY_HD double spicey_max_nan(double a, double b) {  // Math.max semantics
   return (a > b || a != a) ? a : b;
 }
 
-// Diode companion model, simulateTRAN.ts:87-98.  `e_in` >= 0: exp(vd/vt) already known and vd unclamped.
-SPICEY_HD void spicey_diode(double vd, double is, double nn, double &gd, double &ieq) {
-  const double vt = nn * SPICEY_VT300;
+// Diode companion model, simulateTRAN.ts:87-98, and (when `want_i`) the recorded current of :214-217,
+// which uses the UNCLAMPED junction voltage.  One exp serves both whenever vd lies inside the clamp
+// window [-1, 0.8].  The per-diode constants 1/(N VT) and Is/(N VT) are formed once per evaluation
+// from Is, N (two divisions); callers on the hot path pass them precomputed.
+SPICEY_HD void spicey_diode_k(double vd, double is, double inv_vt, double is_vt, bool want_i, double &gd, double &ieq, double &irec) {
   double vl = vd;
   if (vd > 0.8) vl = 0.8;
   if (vd < -1.0) vl = -1.0;
-  const double e = exp(vl / vt);
+  const double e = exp(vl * inv_vt);
   const double id = is * (e - 1.0);
-  gd = spicey_max_nan((is / vt) * e, 1e-12);
+  gd = spicey_max_nan(is_vt * e, 1e-12);
   ieq = id - gd * vl;
+  irec = id;
+  if (want_i && vl != vd) irec = is * (exp(vd * inv_vt) - 1.0);
+}
+SPICEY_HD void spicey_diode(double vd, double is, double nn, double &gd, double &ieq) {
+  const double vt = nn * SPICEY_VT300;
+  double irec;
+  spicey_diode_k(vd, is, 1.0 / vt, is / vt, false, gd, ieq, irec);
 }
 
 SPICEY_HD double spicey_switch_g(int on, double ron, double roff) {  // simulateTRAN.ts:59-61
@@ -106,6 +131,12 @@ struct TranPhases {
         else if (i < P.nR + P.nC + P.nL) v = dtc / R.L_val[in * P.nL + (i - P.nR - P.nC)];
         else v = 1.0;
         g[i] = v;
+      }
+      SPICEY_NOUNROLL
+      for (int i = tid; i < P.nD; i += T) {
+        const double vt = R.D_n[in * P.nD + i] * SPICEY_VT300;
+        R.dpar[(in * P.nD + i) * 2 + 0] = 1.0 / vt;
+        R.dpar[(in * P.nD + i) * 2 + 1] = R.D_is[in * P.nD + i] / vt;
       }
     }
   }
@@ -159,14 +190,15 @@ struct TranPhases {
         c.u[(size_t)(oD + i) * K + k] = q;
       }
     }
-    static_copy(tid);
+    static_copy(tid, true);
     if (tid == 0) c.flags[0] = 0;
   }
-  SPICEY_HD void static_copy(int tid) const {
+  SPICEY_HD void static_copy(int tid, bool all = false) const {
+    const int ne = all ? P.nLU : P.nRestore;  // entries >= nRestore are never written after the first copy
     for (int k = 0; k < K; k++) {
       const double *sv = R.statv + (size_t)c.inst[k] * P.nLU;
       SPICEY_NOUNROLL
-      for (int e = tid; e < P.nLU; e += T) c.W[(size_t)e * K + k] = sv[e];
+      for (int e = tid; e < ne; e += T) c.W[(size_t)e * K + k] = sv[e];
     }
   }
 
@@ -187,7 +219,7 @@ struct TranPhases {
         }
         if (et & SPICEY_TGT_RECIP) {
           if (fabs(v) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
-          v = 1.0 / v;
+          v = spicey_rcp(v);
         }
         c.W[(size_t)e * K + k] = v;
       }
@@ -230,7 +262,7 @@ struct TranPhases {
       if (tgt & SPICEY_TGT_RECIP) {
         for (int k = 0; k < K; k++) {
           if (fabs(acc[k]) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
-          acc[k] = 1.0 / acc[k];
+          acc[k] = spicey_rcp(acc[k]);
         }
       }
       for (int k = 0; k < K; k++) c.W[(size_t)ti * K + k] = acc[k];
@@ -344,10 +376,11 @@ struct TranPhases {
       SPICEY_NOUNROLL
       for (int i = tid; i < P.nD; i += T) {
         const double vd = volt(P.D_a[i], k) - volt(P.D_b[i], k);
-        const double is = R.D_is[in * P.nD + i], nn = R.D_n[in * P.nD + i];
-        if (cur) oi[cD + i] = is * (exp(vd / (nn * SPICEY_VT300)) - 1.0);  // unclamped, simulateTRAN.ts:214-217
-        double gg, q;
-        spicey_diode(vd, is, nn, gg, q);
+        const double is = R.D_is[in * P.nD + i];
+        const double *dp = R.dpar + (in * P.nD + i) * 2;  // {1/(N VT), Is/(N VT)} from the prologue
+        double gg, q, irec;
+        spicey_diode_k(vd, is, dp[0], dp[1], cur, gg, q, irec);
+        if (cur) oi[cD + i] = irec;  // unclamped, simulateTRAN.ts:214-217
         c.gd[(size_t)(P.nS + i) * K + k] = gg;
         c.u[(size_t)(oD + i) * K + k] = q;
         if (last) R.D_vdprev[in * P.nD + i] = vd;
@@ -362,10 +395,15 @@ struct TranPhases {
 // thread keeps its share as RMAX 16-byte records in VGPRs for the whole transient (the register file,
 // 512 KB per CU, is the largest low-latency store of the chip); only phases that do not fit are
 // streamed from L2.  Each (wave, slot) chunk belongs to one phase, so dispatch is wave-uniform.
-template <int RMAX>
+template <int K, int RMAX, int NSV>
 struct ResRegs {
-  uint32_t w[RMAX][4];
-  int32_t ph[RMAX];
+  uint32_t w[RMAX][4];  // factor / backward task records
+  int32_t ph[RMAX];     // phase of each slot (wave-uniform)
+  double sv[NSV][K];    // static part of the entries this thread owns (e = tid + j T)
+  uint32_t dd[NSV];     // their dynamic-stamp descriptors
+  uint32_t rhs[2];      // right-hand-side descriptor of row tid
+  uint32_t eR, eC, eL, eD, ox;  // packed terminals of element tid of each kind; W index of output tid
+  double vprev[K];      // vPrev of capacitor tid (simulateTRAN.ts:221-225), exact
 };
 
 template <int K, bool KTASK>
@@ -414,16 +452,16 @@ SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_
     if (meta & (SPICEY_R16_RECIP << 8)) {
       for (int k = 0; k < K; k++) {
         if (fabs(acc[k]) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
-        acc[k] = 1.0 / acc[k];
+        acc[k] = spicey_rcp(acc[k]);
       }
     }
     for (int k = 0; k < K; k++) c.W[(size_t)tgt * K + k] = acc[k];
   }
 }
 
-template <int K, int RMAX, bool KTASK>
-SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, const WgCtx<K> &c, const ResRegs<RMAX> &rr, int tid,
-                               int T, int p) {
+template <int K, int RMAX, int NSV, bool KTASK>
+SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, const WgCtx<K> &c, const ResRegs<K, RMAX, NSV> &rr, int tid,
+                               int T, int p, bool streamed) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -433,6 +471,7 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
       SPICEY_OPAQUE(w0); SPICEY_OPAQUE(w1); SPICEY_OPAQUE(w2); SPICEY_OPAQUE(w3);
       spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3);
     }
+  if (!streamed) return;
   const uint32_t sc = Q.st_cnt[p];
   if (sc) {
     const uint32_t *base = P.rec16 + (size_t)Q.st_first[p] * 4;
@@ -443,43 +482,310 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
   }
 }
 
-template <int K, int RMAX, class Exec>
-SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, WgCtx<K> &c, int wg) {
-  const int T = ex.threads();
-  TranPhases<K> ph{P, R, c, T};
-  ex.phase(SPICEY_PH_PRO, [&](int tid) {
-    if (tid == 0) { c.flags[0] = 0; c.flags[1] = 0; c.flags[2] = -1; }
-    ph.p0_gstat(tid);
-    ResRegs<RMAX> &rr = ex.template regs<RMAX>(tid);
+// v2 versions of the B and Z phases: everything step-invariant that a thread needs (static entry values,
+// stamp / right-hand-side descriptors, element terminals, vPrev) sits in its registers; items beyond the
+// resident capacity (entries >= NSV*T, rows / elements >= T) take the streamed remainder loops.
+// Difference to v1: u[c] holds the capacitor companion CURRENT gc*vPrev (so the right-hand side is a
+// pure +-1 gather, stampCurrentReal.ts:12-13) and the exact vPrev lives in a register.
+template <int K, int RMAX, int NSV>
+struct TranPhases2 {
+  const SpiceyProg &P;
+  const SpiceyRun &R;
+  WgCtx<K> &c;
+  int T;
+  typedef ResRegs<K, RMAX, NSV> Regs;
+
+  SPICEY_HD double volt16(uint32_t xi, int k) const { return xi == 0xFFFFu ? 0.0 : c.W[(size_t)xi * K + k]; }
+  SPICEY_HD double dv16(uint32_t ab, int k) const { return volt16(ab & 0xFFFFu, k) - volt16(ab >> 16, k); }
+
+  SPICEY_HD void load_resident(int tid, const SpiceyResident &Q, Regs &rr) const {
     for (int s = 0; s < RMAX; s++) {
       const bool have = s < Q.rmax;
       const uint32_t *src = Q.res + ((size_t)(have ? s : 0) * T + tid) * 4;
       for (int w = 0; w < 4; w++) rr.w[s][w] = have ? src[w] : 0u;
       rr.ph[s] = have ? SPICEY_UNIFORM(Q.res_phase[(size_t)(tid >> 6) * Q.rmax + s]) : -1;
     }
+    rr.rhs[0] = rr.rhs[1] = 0;
+    if (tid < P.n) { rr.rhs[0] = P.row_desc[(size_t)tid * 2]; rr.rhs[1] = P.row_desc[(size_t)tid * 2 + 1]; }
+    rr.eR = tid < P.nR ? P.R_ab[tid] : 0xFFFFFFFFu;
+    rr.eC = tid < P.nC ? P.C_ab[tid] : 0xFFFFFFFFu;
+    rr.eL = tid < P.nL ? P.L_ab[tid] : 0xFFFFFFFFu;
+    rr.eD = tid < P.nD ? P.D_ab[tid] : 0xFFFFFFFFu;
+    rr.ox = tid < P.nOut ? (P.out_x[tid] < 0 ? 0xFFFFu : (uint32_t)P.out_x[tid]) : 0xFFFFu;
+  }
+  // after p1_static: static entry values into registers; elements from the state entering the run
+  SPICEY_HD void a0_initial(int tid, Regs &rr) const {
+    const int oL = P.nC, oV = P.nC + P.nL, oD = P.nC + P.nL + P.nV;
+    for (int j = 0; j < NSV; j++) {
+      const int e = tid + j * T;
+      rr.dd[j] = e < P.nRestore ? P.ent_dd[e] : 0x80000000u;  // bit 31 = "not mine to stamp"
+      for (int k = 0; k < K; k++) rr.sv[j][k] = e < P.nRestore ? R.statv[(size_t)c.inst[k] * P.nLU + e] : 0.0;
+    }
+    for (int k = 0; k < K; k++) {  // entries that no phase ever writes: stamped once per run
+      const double *sv = R.statv + (size_t)c.inst[k] * P.nLU;
+      SPICEY_NOUNROLL
+      for (int e = P.nRestore + tid; e < P.nLU; e += T) c.W[(size_t)e * K + k] = sv[e];
+    }
+    for (int k = 0; k < K; k++) {
+      const size_t in = (size_t)c.inst[k];
+      const double *g = R.gstat + in * P.nGstat;
+      rr.vprev[k] = tid < P.nC ? R.C_vprev[in * P.nC + tid] : 0.0;
+      SPICEY_NOUNROLL
+      for (int i = tid; i < P.nC; i += T) c.u[(size_t)i * K + k] = g[P.nR + i] * R.C_vprev[in * P.nC + i];
+      SPICEY_NOUNROLL
+      for (int i = tid; i < P.nL; i += T) c.u[(size_t)(oL + i) * K + k] = R.L_iprev[in * P.nL + i];
+      SPICEY_NOUNROLL
+      for (int i = tid; i < P.nV; i += T) c.u[(size_t)(oV + i) * K + k] = R.src[i];
+      SPICEY_NOUNROLL
+      for (int i = tid; i < P.nS; i += T) {
+        const int on = R.S_ison[in * P.nS + i];
+        c.ison[(size_t)i * K + k] = on;
+        c.gd[(size_t)i * K + k] = spicey_switch_g(on, R.S_ron[in * P.nS + i], R.S_roff[in * P.nS + i]);
+      }
+      SPICEY_NOUNROLL
+      for (int i = tid; i < P.nD; i += T) {
+        const double *dp = R.dpar + (in * P.nD + i) * 2;
+        double g2, q, irec;
+        spicey_diode_k(R.D_vdprev[in * P.nD + i], R.D_is[in * P.nD + i], dp[0], dp[1], false, g2, q, irec);
+        c.gd[(size_t)(P.nS + i) * K + k] = g2;
+        c.u[(size_t)(oD + i) * K + k] = q;
+      }
+    }
+    if (tid == 0) c.flags[0] = 0;
+  }
+
+  SPICEY_HD void stamp_entry(uint32_t e, uint32_t dd, const double *sv) const {  // sv[K]
+    double v[K];
+    for (int k = 0; k < K; k++) v[k] = sv[k];
+    const uint32_t f0 = dd & 0x7fffu, f1 = (dd >> 15) & 0x7fffu;
+    if (f0) {
+      const uint32_t ix = (f0 & 0x3fffu) - 1;
+      for (int k = 0; k < K; k++) { const double g = c.gd[(size_t)ix * K + k]; v[k] = (f0 & 0x4000u) ? v[k] - g : v[k] + g; }
+    }
+    if (f1) {
+      const uint32_t ix = (f1 & 0x3fffu) - 1;
+      for (int k = 0; k < K; k++) { const double g = c.gd[(size_t)ix * K + k]; v[k] = (f1 & 0x4000u) ? v[k] - g : v[k] + g; }
+    }
+    if (dd & (1u << 30))
+      for (int k = 0; k < K; k++) {
+        if (fabs(v[k]) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
+        v[k] = spicey_rcp(v[k]);
+      }
+    for (int k = 0; k < K; k++) c.W[(size_t)e * K + k] = v[k];
+  }
+  SPICEY_HD void rhs_row(uint32_t r, uint32_t d0, uint32_t d1) const {
+    double acc[K];
+    for (int k = 0; k < K; k++) acc[k] = 0.0;
+    const uint32_t f[4] = {d0 & 0xffffu, d0 >> 16, d1 & 0xffffu, d1 >> 16};
+    for (int i = 0; i < 4; i++)
+      if (f[i]) {
+        const uint32_t ix = (f[i] & 0x7fffu) - 1;
+        for (int k = 0; k < K; k++) { const double t = c.u[(size_t)ix * K + k]; acc[k] = (f[i] & 0x8000u) ? acc[k] - t : acc[k] + t; }
+      }
+    for (int k = 0; k < K; k++) c.W[(size_t)(P.nLU + r) * K + k] = acc[k];
+  }
+
+  // ---- B: matrix = static + dynamic stamps; right-hand side -----------------------------------------
+  SPICEY_HD void b_stamp(int tid, const Regs &rr) const {
+    if (tid == 0) c.flags[0] = 0;
+    for (int j = 0; j < NSV; j++) {
+      const uint32_t e = (uint32_t)(tid + j * T);
+      uint32_t dd = rr.dd[j];
+      SPICEY_OPAQUE(dd);
+      if (!(dd >> 31)) stamp_entry(e, dd, rr.sv[j]);
+    }
+    SPICEY_NOUNROLL
+    for (int e = tid + NSV * T; e < P.nRestore; e += T) {  // entries beyond the resident capacity
+      const uint32_t dd = P.ent_dd[e];
+      if (dd >> 31) continue;
+      double sv[K];
+      for (int k = 0; k < K; k++) sv[k] = R.statv[(size_t)c.inst[k] * P.nLU + e];
+      stamp_entry((uint32_t)e, dd, sv);
+    }
+    SPICEY_NOUNROLL
+    for (int t = tid; t < P.nDynX; t += T) {  // entries with > 2 dynamic stamps
+      const uint32_t et = P.dynx_ent[t], e = SPICEY_IDX(et);
+      for (int k = 0; k < K; k++) {
+        double v = R.statv[(size_t)c.inst[k] * P.nLU + e];
+        for (uint32_t j = P.dynx_ptr[t]; j < P.dynx_ptr[t + 1]; j++) {
+          const uint32_t ix = P.dynx_idx[j];
+          const double g = c.gd[(size_t)SPICEY_IDX(ix) * K + k];
+          v = (ix & SPICEY_NEG) ? v - g : v + g;
+        }
+        if (et & SPICEY_TGT_RECIP) {
+          if (fabs(v) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
+          v = spicey_rcp(v);
+        }
+        c.W[(size_t)e * K + k] = v;
+      }
+    }
+    if (tid < P.n) {
+      uint32_t d0 = rr.rhs[0], d1 = rr.rhs[1];
+      SPICEY_OPAQUE(d0); SPICEY_OPAQUE(d1);
+      if (d1 != 0xFFFFFFFFu) rhs_row((uint32_t)tid, d0, d1);
+    }
+    SPICEY_NOUNROLL
+    for (int r = tid + T; r < P.n; r += T) {
+      const uint32_t d0 = P.row_desc[(size_t)r * 2], d1 = P.row_desc[(size_t)r * 2 + 1];
+      if (d1 != 0xFFFFFFFFu) rhs_row((uint32_t)r, d0, d1);
+    }
+    SPICEY_NOUNROLL
+    for (int t = tid; t < P.nRowX; t += T) {  // rows with > 4 contributions: +-1 gather from the CSR lists
+      const uint32_t r = P.rowx[t];
+      for (int k = 0; k < K; k++) {
+        double acc = 0.0;
+        for (uint32_t j = P.rhs_ptr[r]; j < P.rhs_ptr[r + 1]; j++) {
+          const uint32_t ix = P.rhs_idx[j];
+          const double t2 = c.u[(size_t)SPICEY_IDX(ix) * K + k];
+          acc = (ix & SPICEY_NEG) ? acc - t2 : acc + t2;
+        }
+        c.W[(size_t)(P.nLU + r) * K + k] = acc;
+      }
+    }
+  }
+
+  SPICEY_HD void a_reiterate(int tid) const {  // iteration >= 1: diodes from x, switches from their new state
+    const int oD = P.nC + P.nL + P.nV;
+    for (int k = 0; k < K; k++) {
+      const size_t in = (size_t)c.inst[k];
+      SPICEY_NOUNROLL
+      for (int i = tid; i < P.nS; i += T)
+        c.gd[(size_t)i * K + k] = spicey_switch_g(c.ison[(size_t)i * K + k], R.S_ron[in * P.nS + i], R.S_roff[in * P.nS + i]);
+      SPICEY_NOUNROLL
+      for (int i = tid; i < P.nD; i += T) {
+        const double *dp = R.dpar + (in * P.nD + i) * 2;
+        double g2, q, irec;
+        spicey_diode_k(dv16(P.D_ab[i], k), R.D_is[in * P.nD + i], dp[0], dp[1], false, g2, q, irec);
+        c.gd[(size_t)(P.nS + i) * K + k] = g2;
+        c.u[(size_t)(oD + i) * K + k] = q;
+      }
+    }
+  }
+
+  // ---- Z: record, update state, evaluate the next step's companions --------------------------------
+  SPICEY_HD void z_cap(int i, uint32_t ab, int k, size_t in, const double *g, double *oi, int cC, double &vprev, bool last) const {
+    const double dv = dv16(ab, k);
+    const double gc = g[P.nR + i];
+    if (oi) oi[cC + i] = gc * (dv - vprev);
+    vprev = dv;
+    c.u[(size_t)i * K + k] = gc * dv;
+    if (last) R.C_vprev[in * P.nC + i] = dv;
+  }
+  SPICEY_HD void z_dio(int i, uint32_t ab, int k, size_t in, double *oi, int cD, int oD, bool last) const {
+    const double vd = dv16(ab, k);
+    const double *dp = R.dpar + (in * P.nD + i) * 2;
+    double gg, q, irec;
+    spicey_diode_k(vd, R.D_is[in * P.nD + i], dp[0], dp[1], oi != nullptr, gg, q, irec);
+    if (oi) oi[cD + i] = irec;
+    c.gd[(size_t)(P.nS + i) * K + k] = gg;
+    c.u[(size_t)(oD + i) * K + k] = q;
+    if (last) R.D_vdprev[in * P.nD + i] = vd;
+  }
+  SPICEY_HD void z_record(int tid, int64_t step, Regs &rr) const {
+    const bool last = step == R.steps;
+    const int oL = P.nC, oV = P.nC + P.nL, oD = P.nC + P.nL + P.nV;
+    const int cR = 0, cC = P.nR, cL = P.nR + P.nC, cV = cL + P.nL, cS = cV + P.nV, cD = cS + P.nS;
+    uint32_t eR = rr.eR, eC = rr.eC, eL = rr.eL, eD = rr.eD, ox = rr.ox;
+    SPICEY_OPAQUE(eR); SPICEY_OPAQUE(eC); SPICEY_OPAQUE(eL); SPICEY_OPAQUE(eD); SPICEY_OPAQUE(ox);
+    // The instance loop is kept ROLLED here (one copy of the exp / store code, one instance's working set):
+    // unrolled and interleaved it needs ~2x the VGPRs and the register-resident program spills.
+    SPICEY_NOUNROLL
+    for (int k = 0; k < K; k++) {
+      const int vk = K == 1 ? c.valid[0] : (k == 0 ? c.valid[0] : c.valid[K - 1]);
+      if (!vk) continue;
+      const size_t in = (size_t)(K == 1 ? c.inst[0] : (k == 0 ? c.inst[0] : c.inst[K - 1]));
+      double *ov = R.out_v + (in * (size_t)(R.steps + 1) + (size_t)step) * P.nOut;
+      double *oi = R.out_i ? R.out_i + (in * (size_t)(R.steps + 1) + (size_t)step) * P.nCur : nullptr;
+      const double *g = R.gstat + in * P.nGstat;
+      if (tid < P.nOut) ov[tid] = volt16(ox, k);
+      SPICEY_NOUNROLL
+      for (int i = tid + T; i < P.nOut; i += T) ov[i] = P.out_x[i] < 0 ? 0.0 : c.W[(size_t)P.out_x[i] * K + k];
+      if (oi) {
+        if (tid < P.nR) oi[cR + tid] = dv16(eR, k) * g[tid];
+        SPICEY_NOUNROLL
+        for (int i = tid + T; i < P.nR; i += T) oi[cR + i] = dv16(P.R_ab[i], k) * g[i];
+      }
+      if (tid < P.nC) {
+        double vp = K == 1 ? rr.vprev[0] : (k == 0 ? rr.vprev[0] : rr.vprev[K - 1]);
+        z_cap(tid, eC, k, in, g, oi, cC, vp, last);
+        if (K == 1 || k == 0) rr.vprev[0] = vp;
+        else rr.vprev[K - 1] = vp;
+      }
+      SPICEY_NOUNROLL
+      for (int i = tid + T; i < P.nC; i += T) {  // beyond the resident capacity: vPrev lives in the state array
+        double vp = R.C_vprev[in * P.nC + i];
+        z_cap(i, P.C_ab[i], k, in, g, oi, cC, vp, false);
+        R.C_vprev[in * P.nC + i] = vp;
+      }
+      SPICEY_NOUNROLL
+      for (int i = tid; i < P.nL; i += T) {
+        const double dv = dv16(i == tid ? eL : P.L_ab[i], k);
+        const double il = g[P.nR + P.nC + i] * dv + c.u[(size_t)(oL + i) * K + k];
+        if (oi) oi[cL + i] = il;
+        c.u[(size_t)(oL + i) * K + k] = il;
+        if (last) R.L_iprev[in * P.nL + i] = il;
+      }
+      SPICEY_NOUNROLL
+      for (int i = tid; i < P.nV; i += T) {
+        if (oi) oi[cV + i] = c.W[(size_t)P.V_x[i] * K + k];
+        if (!last) c.u[(size_t)(oV + i) * K + k] = R.src[(size_t)(step + 1) * P.nV + i];
+      }
+      SPICEY_NOUNROLL
+      for (int i = tid; i < P.nS; i += T) {
+        const int on = c.ison[(size_t)i * K + k];
+        const double gs = spicey_switch_g(on, R.S_ron[in * P.nS + i], R.S_roff[in * P.nS + i]);
+        const double va = P.S_a[i] < 0 ? 0.0 : c.W[(size_t)P.S_a[i] * K + k], vb = P.S_b[i] < 0 ? 0.0 : c.W[(size_t)P.S_b[i] * K + k];
+        if (oi) oi[cS + i] = (va - vb) * gs;
+        c.gd[(size_t)i * K + k] = gs;
+        if (last) R.S_ison[in * P.nS + i] = on;
+      }
+      if (tid < P.nD) z_dio(tid, eD, k, in, oi, cD, oD, last);
+      SPICEY_NOUNROLL
+      for (int i = tid + T; i < P.nD; i += T) z_dio(i, P.D_ab[i], k, in, oi, cD, oD, last);
+      SPICEY_SCHED_FENCE;
+    }
+  }
+};
+
+template <int K, int RMAX, int NSV, class Exec>
+SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, WgCtx<K> &c, int wg) {
+  const int T = ex.threads();
+  TranPhases<K> ph{P, R, c, T};
+  TranPhases2<K, RMAX, NSV> p2{P, R, c, T};
+  typedef ResRegs<K, RMAX, NSV> Regs;
+  ex.phase(SPICEY_PH_PRO, [&](int tid) {
+    if (tid == 0) { c.flags[0] = 0; c.flags[1] = 0; c.flags[2] = -1; }
+    ph.p0_gstat(tid);
+    p2.load_resident(tid, Q, ex.template regs<Regs>(tid));
   });
   ex.phase(SPICEY_PH_PRO, [&](int tid) { ph.p1_static(tid); });
-  ex.phase(SPICEY_PH_PRO, [&](int tid) { ph.a0_initial(tid); });
+  ex.phase(SPICEY_PH_PRO, [&](int tid) { p2.a0_initial(tid, ex.template regs<Regs>(tid)); });
   unsigned long long solves = 0;
   int32_t code = 0;
   int64_t err_step = 0;
   int32_t err_iter = 0;
   if (c.flags[1]) { code = 1; }
   const int nL = P.nLevels;
+  // which phases have work: kept in a scalar mask so that the phase loop issues no loads
+  unsigned long long active = 0, smask = 0;
+  for (int p = 0; p < 2 * nL && p < 64; p++) {
+    if (SPICEY_UNIFORM((int)P.ph_cnt[p]) != 0) active |= 1ull << p;
+    if (SPICEY_UNIFORM((int)Q.st_cnt[p]) != 0) smask |= 1ull << p;
+  }
   for (int64_t step = 0; step <= R.steps && code == 0; step++) {
     int iter = 0;
     for (;;) {
-      ex.phase(SPICEY_PH_B, [&](int tid) { ph.b_stamp(tid); });
+      ex.phase(SPICEY_PH_B, [&](int tid) { p2.b_stamp(tid, ex.template regs<Regs>(tid)); });
       for (int p = 0; p < nL; p++) {
-        if (P.ph_cnt[p] == 0) continue;
+        if (p < 64 ? !((active >> p) & 1) : P.ph_cnt[p] == 0) continue;
         ex.phase(SPICEY_PH_U0 + (p < 31 ? p : 31), [&](int tid) {
-          spicey_uk_phase<K, RMAX, false>(P, Q, c, ex.template regs<RMAX>(tid), tid, T, p);
+          spicey_uk_phase<K, RMAX, NSV, false>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
         });
       }
       for (int p = nL; p < 2 * nL; p++) {
         const int l = 2 * nL - 1 - p;
         ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) {
-          spicey_uk_phase<K, RMAX, true>(P, Q, c, ex.template regs<RMAX>(tid), tid, T, p);
+          spicey_uk_phase<K, RMAX, NSV, true>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
         });
       }
       if (c.flags[1]) { code = 1; err_step = step; err_iter = iter; break; }
@@ -488,7 +794,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
       const int switched = c.flags[0];
       if (!switched || iter == SPICEY_MAX_ITER - 1) break;
       iter++;
-      ex.phase(SPICEY_PH_A, [&](int tid) { ph.a_reiterate(tid); });
+      ex.phase(SPICEY_PH_A, [&](int tid) { p2.a_reiterate(tid); });
     }
     if (code) break;
     {
@@ -500,7 +806,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
       if (tid == 0 && R.iters)
         for (int k = 0; k < K; k++)
           if (c.valid[k]) R.iters[(size_t)c.inst[k] * (size_t)(R.steps + 1) + (size_t)step] = iter + 1;
-      ph.z_record(tid, step);
+      p2.z_record(tid, step, ex.template regs<Regs>(tid));
     });
   }
   ex.phase(SPICEY_PH_PRO, [&](int tid) {

@@ -46,7 +46,7 @@ def bits_equal(a, b):
 
 
 SMALL_GOLDENS = ["two_probes", "transient01", "case_insensitive", "switch_vt_vh", "vswitch_pwl", "diode_switch",
-                 "boost_probe", "bridge_rectifier", "bridge_bleed", "lc_tank", "relay_osc", "half_bridge", "units_title", "float_cap",
+                 "boost_probe", "bridge_rectifier", "bridge_bleed", "star_hub", "lc_tank", "relay_osc", "half_bridge", "units_title", "float_cap",
                  "steps_round", "ladder20", "dchain20", "mesh6", "mesh9x5"]
 LARGE_GOLDENS = ["rc1000_200", "dchain1000_200", "mesh20_30"]
 

@@ -18,12 +18,11 @@ namespace {
 struct SeqExec {
   int T;
   bool reverse;
-  std::vector<ResRegs<16>> *rr = nullptr;  // per-thread "registers" of the v2 interpreter
+  void *rr = nullptr;  // per-thread "registers" of the v2 interpreter: std::vector<Regs>*
   int threads() const { return T; }
-  template <int RMAX>
-  ResRegs<RMAX> &regs(int tid) {
-    static_assert(RMAX == 16, "emulator instantiates RMAX = 16");
-    return (*rr)[tid];
+  template <class Regs>
+  Regs &regs(int tid) {
+    return (*static_cast<std::vector<Regs> *>(rr))[tid];
   }
   template <class F>
   void phase(int, F f) {
@@ -54,9 +53,10 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
       HostResident hr;
       spicey_build_resident(hp, T, rmax, hr);
       SpiceyResident Q = hr.bind(hr.blob.data());
-      std::vector<ResRegs<16>> regs(T);
+      // NSV = 2 resident entries per thread: small on purpose so that tests also cover the streamed remainder
+      std::vector<ResRegs<K, 16, 2>> regs(T);
       ex.rr = &regs;
-      spicey_tran_run_v2<K, 16>(ex, P, Q, R, c, g);
+      spicey_tran_run_v2<K, 16, 2>(ex, P, Q, R, c, g);
     }
   }
 }
@@ -91,7 +91,8 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
   R.D_is = d->D_is; R.D_n = d->D_n;
   R.C_vprev = C_vprev; R.L_iprev = L_iprev; R.D_vdprev = D_vdprev; R.S_ison = S_ison;
   std::vector<double> gstat((size_t)ni * P.nGstat), statv((size_t)ni * P.nLU), rcoef((size_t)ni * (P.nRhsIdx + 1));
-  R.gstat = gstat.data(); R.statv = statv.data(); R.rcoef = rcoef.data();
+  std::vector<double> dpar((size_t)ni * (P.nD + 1) * 2);
+  R.gstat = gstat.data(); R.statv = statv.data(); R.rcoef = rcoef.data(); R.dpar = dpar.data();
   R.src = src; R.out_v = out_v; R.out_i = out_i; R.iters = iters;
   const int ngroups = (ni + K - 1) / K;
   std::vector<int32_t> status((size_t)ngroups * 4);

@@ -31,7 +31,7 @@ NODE = ["node", "--harmony-nullish", "--harmony-optional-chaining", "--max-old-s
 # name -> (netlist file, repeat)
 SMALL = {
     "readme_rc": 1, "two_probes": 2, "transient01": 1, "case_insensitive": 1, "switch_vt_vh": 1,
-    "vswitch_pwl": 1, "diode_switch": 2, "boost_probe": 1, "bridge_rectifier": 1, "bridge_bleed": 1, "lc_tank": 1,
+    "vswitch_pwl": 1, "diode_switch": 2, "boost_probe": 1, "bridge_rectifier": 1, "bridge_bleed": 1, "star_hub": 1, "lc_tank": 1,
     "relay_osc": 1, "half_bridge": 2, "units_title": 1, "float_cap": 1, "steps_round": 1,
     "err_singular": 1, "err_vloop": 1,
 }
