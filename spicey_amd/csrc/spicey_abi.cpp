@@ -4,6 +4,7 @@
 // point that would compute returns SPICEY_ERR_NO_DEVICE.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -84,9 +85,21 @@ extern "C" void spicey_destroy(SpiceyHandle *h) {
   delete h;
 }
 
-static int pick_threads(const HostProgram &hp) {
-  // widest phase decides: one lane per task, one or two tasks per lane
-  const int n = hp.hdr.n;
+static int pick_threads(const HostProgram &hp, bool v2) {
+  const SpiceyProg &P = hp.hdr;
+  if (v2) {
+    // smallest workgroup in which the whole program is register-resident: all factor/backward tasks in the
+    // RMAX slots, one right-hand-side row, one element of each kind and NSV re-stamped entries per thread
+    int64_t chunks = 0;  // 64-lane chunks of task records
+    for (uint32_t c : hp.ph_cnt) chunks += (c + 63) / 64;
+    const int widest = std::max(std::max(std::max(P.n, P.nOut), std::max(P.nR, P.nC)), std::max(P.nD, P.nL));
+    for (int T = 64; T <= 1024; T *= 2) {
+      const int rmax = spicey_v2_rmax(T), nsv = T <= 512 ? 8 : 4;
+      if (chunks <= (int64_t)rmax * (T / 64) && widest <= T && P.nRestore <= nsv * T) return T;
+    }
+    return 1024;
+  }
+  const int n = P.n;
   if (n <= 48) return 64;
   if (n <= 160) return 128;
   if (n <= 400) return 256;
@@ -137,11 +150,8 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   const bool want_lds = !h->opt.force_global;
   if (K != 0 && K != 1 && K != 2 && K != 4) { h->err = "inst_per_wg must be 0, 1, 2 or 4"; return fail(SPICEY_ERR_BAD_DESC); }
   if (P.nS > 0) K = 1;  // the switch iteration count is per instance: no interleaving
-  if (K == 0) {
-    K = 1;
-    // interleave two instances when that still leaves every CU a workgroup and fits LDS
-    if (want_lds && h->n_inst >= 2 * ncu && spicey_lds_bytes(P, 2, true) <= SPICEY_LDS_MAX) K = 2;
-  }
+  if (K == 0) K = 1;  // measured: one instance per workgroup beats two interleaved ones (VGPR pressure in phase Z)
+  (void)ncu;
   if (K > h->n_inst) K = 1;
   h->lds = want_lds && spicey_lds_bytes(P, K, true) <= SPICEY_LDS_MAX;
   if (!h->lds && want_lds && K > 1) {
@@ -149,14 +159,14 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
     h->lds = spicey_lds_bytes(P, 1, true) <= SPICEY_LDS_MAX;
   }
   h->K = K;
-  h->T = h->opt.threads > 0 ? h->opt.threads : pick_threads(h->hp);
-  if (h->T > 1024 || (h->T & 63)) { h->err = "threads must be a multiple of 64, <= 1024"; return fail(SPICEY_ERR_BAD_DESC); }
-  h->grid = (h->n_inst + K - 1) / K;
-  h->lds_bytes = spicey_lds_bytes(P, K, h->lds);
   // interpreter: v2 needs the LDS workspace, 16-bit records and K <= 2
   const bool v2_ok = h->lds && P.has16 && K <= 2;
   if (h->opt.interpreter == 2 && !v2_ok) { h->err = "interpreter 2 needs the LDS workspace, < 65536 workspace entries and inst_per_wg <= 2"; return fail(SPICEY_ERR_BAD_DESC); }
   h->interp = (h->opt.interpreter == 1 || !v2_ok) ? 1 : 2;
+  h->T = h->opt.threads > 0 ? h->opt.threads : pick_threads(h->hp, h->interp == 2);
+  if (h->T > 1024 || (h->T & 63) || h->T < 64) { h->err = "threads must be a multiple of 64 in [64, 1024]"; return fail(SPICEY_ERR_BAD_DESC); }
+  h->grid = (h->n_inst + K - 1) / K;
+  h->lds_bytes = spicey_lds_bytes(P, K, h->lds);
   if (h->interp == 2) spicey_build_resident(h->hp, h->T, spicey_v2_rmax(h->T), h->hres);
 
   // ---- uploads -----------------------------------------------------------------------------------
