@@ -38,6 +38,23 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic(solves_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes).  Counters
+    cannot be read from inside the timed run, so the value is only reported when the committed measurement
+    was taken on the same workload (same solves per launch); otherwise null."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                t = json.load(fh)
+            if int(t["solves_per_launch"]) == int(solves_per_launch):
+                return float(t["traffic_bytes_per_launch"]), os.path.basename(f)
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
+
+
 def cpu_baseline(workload, n, seconds_target=12.0):
     """Oracle (bit-exact restatement of the reference's dense-GE algorithm), 1 thread, bounded sample."""
     from oracle.pyoracle import OracleBackend
@@ -149,6 +166,7 @@ def main():
         solves_per_launch = solves_rank / args.steps
         algo = info["algorithmic_bytes_solve"]
         achieved = algo * solves_per_launch / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(solves_per_launch)
         rec = {
             "metric": "Newton-LU timestep solves/sec, 1000-node netlist",
             "value": total_solves / el,
@@ -170,12 +188,13 @@ def main():
                 "instances_total": B * n_gpus, "parallelism": f"instance-sharded x{n_gpus}, no data-path collective",
                 "inst_per_workgroup": info["inst_per_wg"], "threads": info["threads"], "lds_bytes": info["lds_bytes"],
                 "nnz_a": info["nnz_a"], "nnz_lu": info["nnz_lu"], "levels": info["n_levels"],
+                "interpreter": info["interpreter"], "resident_tasks": info["resident_tasks"], "streamed_tasks": info["streamed_tasks"],
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_solve": algo, "solves_per_launch": solves_per_launch, "kernel_ms": k_ms,
-                "kernel": "spicey_tran_kernel",
+                "kernel": "spicey_tran_kernel_v2" if info.get("interpreter") == 2 else "spicey_tran_kernel",
             },
             "results_finite": finite,
         }
