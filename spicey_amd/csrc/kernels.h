@@ -13,5 +13,8 @@ hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bo
 
 // v2 (register-resident program): slots per thread for a workgroup size, and the launcher (K in {1, 2})
 int spicey_v2_rmax(int threads);
+int spicey_v2_nsv(int threads);
+int spicey_v2_nel(int threads);
+int spicey_v2_max_threads(int K);
 hipError_t spicey_launch_tran_v2(const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, int K, int grid, int threads,
                                  hipStream_t st);

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(1024) spicey_tran_kernel(SpiceyProg P, SpiceyR
 // v2: register-resident program (LDS workspace only; 16-bit records)
 template <class Regs>
 struct GpuExecV2 {
-  unsigned long long *prof;
+  unsigned long long *prof;  // LDS accumulators [SPICEY_PH_SLOTS] when profiling, else null
   Regs rr;
   __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
   template <class R2>
@@ -83,12 +83,12 @@ struct GpuExecV2 {
     asm volatile("" : "+v"(tid));
     f(tid);
     __syncthreads();
-    if (prof && threadIdx.x == 0) prof[tag] += (unsigned long long)(clock64() - t0);
+    if (prof && threadIdx.x == 0) atomicAdd(&prof[tag], (unsigned long long)(clock64() - t0));  // LDS: no stall
   }
 };
 
-template <int K, int RMAX, int NSV, int MAXT>
-__global__ void __launch_bounds__(MAXT) spicey_tran_kernel_v2(SpiceyProg P, SpiceyResident Q, SpiceyRun R) {
+template <int K, int RMAX, int NSV, int NEL, int MAXT, int MINW>
+__global__ void __launch_bounds__(MAXT, MINW) spicey_tran_kernel_v2(SpiceyProg P, SpiceyResident Q, SpiceyRun R) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WgCtx<K> c;
   const int wg = (int)blockIdx.x;
@@ -104,14 +104,31 @@ __global__ void __launch_bounds__(MAXT) spicey_tran_kernel_v2(SpiceyProg P, Spic
     c.valid[k] = in < R.n_inst;
     c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
   }
-  GpuExecV2<ResRegs<K, RMAX, NSV>> ex;
-  ex.prof = R.prof ? R.prof + (size_t)wg * SPICEY_PH_SLOTS : nullptr;
-  spicey_tran_run_v2<K, RMAX, NSV>(ex, P, Q, R, c, wg);
+  GpuExecV2<ResRegs<K, RMAX, NSV, NEL>> ex;
+  // profiling accumulators live in LDS behind the flags (576 B, reserved by spicey_lds_bytes)
+  unsigned long long *lprof = (unsigned long long *)(((uintptr_t)(c.flags + 4) + 7) & ~(uintptr_t)7);
+  ex.prof = R.prof ? lprof : nullptr;
+  long long c0 = 0, w0 = 0;
+  if (R.prof) {
+    for (int i = (int)threadIdx.x; i < SPICEY_PH_SLOTS; i += (int)blockDim.x) lprof[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) { c0 = clock64(); w0 = wall_clock64(); }
+  }
+  spicey_tran_run_v2<K, RMAX, NSV, NEL>(ex, P, Q, R, c, wg);
+  if (R.prof) {
+    __syncthreads();
+    if (threadIdx.x == 0) {  // slots 5/6: whole-run shader cycles and 100 MHz wall ticks -> effective clock
+      lprof[5] = (unsigned long long)(clock64() - c0);
+      lprof[6] = (unsigned long long)(wall_clock64() - w0);
+    }
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < SPICEY_PH_SLOTS; i += (int)blockDim.x) R.prof[(size_t)wg * SPICEY_PH_SLOTS + i] = lprof[i];
+  }
 }
 
-template <int K, int RMAX, int NSV, int MAXT>
+template <int K, int RMAX, int NSV, int NEL, int MAXT, int MINW>
 hipError_t launch_v2_t(const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, int grid, int threads, size_t lds, hipStream_t st) {
-  auto kern = spicey_tran_kernel_v2<K, RMAX, NSV, MAXT>;
+  auto kern = spicey_tran_kernel_v2<K, RMAX, NSV, NEL, MAXT, MINW>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -136,6 +153,7 @@ hipError_t launch_t(const SpiceyProg &P, const SpiceyRun &R, int grid, int threa
 size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds) {
   if (!lds) return 64;
   size_t b = ((size_t)P.nW + P.nU + P.nGdyn) * K * sizeof(double) + ((size_t)P.nS * K + 4) * sizeof(int32_t);
+  b = ((b + 15) & ~size_t(15)) + SPICEY_PH_SLOTS * sizeof(unsigned long long);  // + profiling accumulators
   return (b + 15) & ~size_t(15);
 }
 
@@ -161,21 +179,30 @@ hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bo
   return hipErrorInvalidValue;
 }
 
-int spicey_v2_rmax(int threads) { return threads <= 512 ? 16 : 8; }
+// v2 geometry per workgroup size.  MINW (waves per SIMD the register budget is cut for) is chosen so that
+// NO variant spills: ROCm 7.2's hipcc places spill stores of values defined in divergent loops where EXEC can
+// be zero (the store is lost and a later reload returns a previous kernel's scratch) — observed as stale vPrev
+// registers; the Makefile therefore fails the build if any kernel reports a non-zero ScratchSize.
+//   T <= 256 : 32 slots, 12 entries, 4 elements per thread (one wave per SIMD: up to 512 VGPRs; K = 1 or 2)
+//   T <= 512 : 16 slots,  8 entries, 2 elements per thread (<= 256 VGPRs; K = 1 only)
+//   T <= 1024:  8 slots,  4 entries, 1 element  per thread (<= 128 VGPRs; K = 1 only)
+int spicey_v2_rmax(int threads) { return threads <= 256 ? 32 : (threads <= 512 ? 16 : 8); }
+int spicey_v2_nsv(int threads) { return threads <= 256 ? 12 : (threads <= 512 ? 8 : 4); }
+int spicey_v2_nel(int threads) { return threads <= 256 ? 4 : (threads <= 512 ? 2 : 1); }
+int spicey_v2_max_threads(int K) { return K == 1 ? 1024 : 256; }
 
 hipError_t spicey_launch_tran_v2(const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, int K, int grid, int threads,
                                  hipStream_t st) {
   const size_t bytes = spicey_lds_bytes(P, K, true);
-  if (threads <= 512) {
+  if (threads <= 256) {
     switch (K) {
-      case 1: return launch_v2_t<1, 16, 8, 512>(P, Q, R, grid, threads, bytes, st);
-      case 2: return launch_v2_t<2, 16, 8, 512>(P, Q, R, grid, threads, bytes, st);
+      case 1: return launch_v2_t<1, 32, 12, 4, 256, 1>(P, Q, R, grid, threads, bytes, st);
+      case 2: return launch_v2_t<2, 32, 12, 4, 256, 1>(P, Q, R, grid, threads, bytes, st);
     }
-  } else {
-    switch (K) {
-      case 1: return launch_v2_t<1, 8, 4, 1024>(P, Q, R, grid, threads, bytes, st);
-      case 2: return launch_v2_t<2, 8, 4, 1024>(P, Q, R, grid, threads, bytes, st);
-    }
+  } else if (threads <= 512) {
+    if (K == 1) return launch_v2_t<1, 16, 8, 2, 512, 2>(P, Q, R, grid, threads, bytes, st);
+  } else if (K == 1) {
+    return launch_v2_t<1, 8, 4, 1, 1024, 4>(P, Q, R, grid, threads, bytes, st);
   }
   return hipErrorInvalidValue;
 }

@@ -85,19 +85,23 @@ extern "C" void spicey_destroy(SpiceyHandle *h) {
   delete h;
 }
 
-static int pick_threads(const HostProgram &hp, bool v2) {
+static int pick_threads(const HostProgram &hp, bool v2, int K) {
   const SpiceyProg &P = hp.hdr;
   if (v2) {
     // smallest workgroup in which the whole program is register-resident: all factor/backward tasks in the
     // RMAX slots, one right-hand-side row, one element of each kind and NSV re-stamped entries per thread
     int64_t chunks = 0;  // 64-lane chunks of task records
     for (uint32_t c : hp.ph_cnt) chunks += (c + 63) / 64;
-    const int widest = std::max(std::max(std::max(P.n, P.nOut), std::max(P.nR, P.nC)), std::max(P.nD, P.nL));
-    for (int T = 64; T <= 1024; T *= 2) {
-      const int rmax = spicey_v2_rmax(T), nsv = T <= 512 ? 8 : 4;
-      if (chunks <= (int64_t)rmax * (T / 64) && widest <= T && P.nRestore <= nsv * T) return T;
+    const int widest = std::max(std::max(P.n, P.nOut), std::max(std::max(P.nR, P.nC), P.nD));
+    // measured on diode_chain(1000): per-step time T=1024 < T=512 < T=256 (more waves hide the issue-bound
+    // phases B/Z); small circuits take the smallest workgroup that holds everything
+    const int tmax = spicey_v2_max_threads(K);
+    for (int T = 64; T <= tmax; T *= 2) {
+      const int rmax = spicey_v2_rmax(T), nsv = spicey_v2_nsv(T), nel = spicey_v2_nel(T);
+      const bool fits = chunks <= (int64_t)rmax * (T / 64) && widest <= nel * T && P.nRestore <= nsv * T;
+      if (fits && (T >= tmax || widest <= T)) return T;  // prefer one element per thread when a larger T offers it
     }
-    return 1024;
+    return tmax;
   }
   const int n = P.n;
   if (n <= 48) return 64;
@@ -163,7 +167,8 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   const bool v2_ok = h->lds && P.has16 && K <= 2;
   if (h->opt.interpreter == 2 && !v2_ok) { h->err = "interpreter 2 needs the LDS workspace, < 65536 workspace entries and inst_per_wg <= 2"; return fail(SPICEY_ERR_BAD_DESC); }
   h->interp = (h->opt.interpreter == 1 || !v2_ok) ? 1 : 2;
-  h->T = h->opt.threads > 0 ? h->opt.threads : pick_threads(h->hp, h->interp == 2);
+  h->T = h->opt.threads > 0 ? h->opt.threads : pick_threads(h->hp, h->interp == 2, K);
+  if (h->interp == 2 && h->T > spicey_v2_max_threads(K)) { h->err = "interpreter 2 with inst_per_wg = 2 supports at most 256 threads"; return fail(SPICEY_ERR_BAD_DESC); }
   if (h->T > 1024 || (h->T & 63) || h->T < 64) { h->err = "threads must be a multiple of 64 in [64, 1024]"; return fail(SPICEY_ERR_BAD_DESC); }
   h->grid = (h->n_inst + K - 1) / K;
   h->lds_bytes = spicey_lds_bytes(P, K, h->lds);

@@ -876,32 +876,54 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
   out.res_phase.assign((size_t)nWaves * rmax, -1);
   out.st_first.assign(std::max(nPh, 1), 0u);
   out.st_cnt.assign(std::max(nPh, 1), 0u);
-  if (hp.hdr.has16) {
+  if (hp.hdr.has16 && nPh <= 254) {
+    // 1. which phases become resident: smallest first (they are pure latency) while chunks remain;
+    //    chunk c of the running count goes to wave c % nWaves, so a phase spreads over the waves
     std::vector<int> order(nPh);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return hp.ph_cnt[a] < hp.ph_cnt[b]; });
+    struct Chunk { int phase, first, count; };
+    std::vector<std::vector<Chunk>> per_wave(nWaves);
+    std::vector<int> load(nWaves, 0);
     int next_chunk = 0;
-    const int total_chunks = nWaves * rmax;
     for (int p : order) {
       const int cnt = (int)hp.ph_cnt[p];
-      const int need = (cnt + 63) / 64;
       if (cnt == 0) continue;
-      if (next_chunk + need > total_chunks) {  // stays streamed
+      const int need = (cnt + 63) / 64;
+      bool fits = true;
+      {
+        std::vector<int> l2 = load;
+        for (int i = 0; i < need; i++) if (++l2[(next_chunk + i) % nWaves] > rmax) fits = false;
+      }
+      if (!fits) {  // stays streamed
         out.st_first[p] = hp.ph_first[p];
         out.st_cnt[p] = hp.ph_cnt[p];
         out.streamed_tasks += cnt;
         continue;
       }
-      for (int i = 0; i < cnt; i++) {
-        const int c = next_chunk + i / 64, wave = c % nWaves, slot = c / nWaves, lane = i % 64;
-        const size_t dst = ((size_t)slot * T + (size_t)wave * 64 + lane) * 4;
-        const size_t src = ((size_t)hp.ph_first[p] + i) * 4;
-        for (int w = 0; w < 4; w++) out.res[dst + w] = hp.rec16[src + w];
+      for (int i = 0; i < need; i++) {
+        const int w = (next_chunk + i) % nWaves;
+        per_wave[w].push_back({p, i * 64, std::min(64, cnt - i * 64)});
+        load[w]++;
       }
-      for (int c = next_chunk; c < next_chunk + need; c++) out.res_phase[(size_t)(c % nWaves) * rmax + c / nWaves] = p;
       next_chunk += need;
       out.resident_tasks += cnt;
     }
+    // 2. per wave: slots in execution (phase) order, so that the kernel walks them with a cursor
+    for (int w = 0; w < nWaves; w++) {
+      std::stable_sort(per_wave[w].begin(), per_wave[w].end(), [](const Chunk &a, const Chunk &b) { return a.phase < b.phase; });
+      for (size_t slot = 0; slot < per_wave[w].size(); slot++) {
+        const Chunk &ch = per_wave[w][slot];
+        out.res_phase[(size_t)w * rmax + slot] = ch.phase;
+        for (int lane = 0; lane < ch.count; lane++) {
+          const size_t dst = ((size_t)slot * T + (size_t)w * 64 + lane) * 4;
+          const size_t src = ((size_t)hp.ph_first[ch.phase] + ch.first + lane) * 4;
+          for (int k = 0; k < 4; k++) out.res[dst + k] = hp.rec16[src + k];
+        }
+      }
+    }
+  } else if (hp.hdr.has16) {
+    for (int p = 0; p < nPh; p++) { out.st_first[p] = hp.ph_first[p]; out.st_cnt[p] = hp.ph_cnt[p]; out.streamed_tasks += hp.ph_cnt[p]; }
   }
   out.pack();
 }

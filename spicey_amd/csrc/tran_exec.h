@@ -395,15 +395,27 @@ struct TranPhases {
 // thread keeps its share as RMAX 16-byte records in VGPRs for the whole transient (the register file,
 // 512 KB per CU, is the largest low-latency store of the chip); only phases that do not fit are
 // streamed from L2.  Each (wave, slot) chunk belongs to one phase, so dispatch is wave-uniform.
-template <int K, int RMAX, int NSV>
+// Register arrays that are indexed with a wave-uniform RUNTIME index (the slot cursor): as native vector
+// types hipcc addresses them through the VGPR index register (s_set_gpr_idx), O(1), instead of a compare
+// chain over all slots or a scratch round trip.
+#if defined(__clang__)
+template <int N> struct U32Vec { typedef uint32_t type __attribute__((ext_vector_type(N))); };
+#else
+template <int N> struct U32Vec { typedef uint32_t type __attribute__((vector_size(N * 4))); };
+#endif
+
+template <int K, int RMAX, int NSV, int NEL>
 struct ResRegs {
-  uint32_t w[RMAX][4];  // factor / backward task records
-  int32_t ph[RMAX];     // phase of each slot (wave-uniform)
-  double sv[NSV][K];    // static part of the entries this thread owns (e = tid + j T)
+  // factor / backward task records, one 16-byte record per slot, word-major; the slots of a wave are sorted
+  // by phase, `phv` holds the phase id of every slot (one byte each, 0xFF = unused), `cursor` the next slot
+  typename U32Vec<RMAX>::type w0, w1, w2, w3;
+  typename U32Vec<RMAX / 4>::type phv;
+  int32_t cursor;
+  double sv[NSV][K];    // static part of the entries this thread re-stamps (e = tid + j T)
   uint32_t dd[NSV];     // their dynamic-stamp descriptors
-  uint32_t rhs[2];      // right-hand-side descriptor of row tid
-  uint32_t eR, eC, eL, eD, ox;  // packed terminals of element tid of each kind; W index of output tid
-  double vprev[K];      // vPrev of capacitor tid (simulateTRAN.ts:221-225), exact
+  uint32_t rhs[NEL][2]; // right-hand-side descriptors of rows tid + j T
+  uint32_t eR[NEL], eC[NEL], eL[NEL], eD[NEL], ox[NEL];  // packed terminals of elements tid + j T; W index of output tid + j T
+  double vprev[NEL][K]; // vPrev of capacitors tid + j T (simulateTRAN.ts:221-225), exact
 };
 
 template <int K, bool KTASK>
@@ -459,18 +471,38 @@ SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_
   }
 }
 
-template <int K, int RMAX, int NSV, bool KTASK>
-SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, const WgCtx<K> &c, const ResRegs<K, RMAX, NSV> &rr, int tid,
+template <int K, int RMAX, int NSV, int NEL, bool KTASK>
+SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, const WgCtx<K> &c, ResRegs<K, RMAX, NSV, NEL> &rr, int tid,
                                int T, int p, bool streamed) {
+  if (RMAX <= 8) {
+    // few slots: a static compare chain (scalar compares on the wave-uniform phase bytes) is cheaper than
+    // indexed register access
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-  for (int s = 0; s < RMAX; s++)
-    if (rr.ph[s] == p) {
-      uint32_t w0 = rr.w[s][0], w1 = rr.w[s][1], w2 = rr.w[s][2], w3 = rr.w[s][3];
+    for (int s = 0; s < RMAX; s++) {
+      const int sp = SPICEY_UNIFORM((int)((rr.phv[s >> 2] >> ((s & 3) * 8)) & 0xffu));
+      if (sp == p) {
+        uint32_t w0 = rr.w0[s], w1 = rr.w1[s], w2 = rr.w2[s], w3 = rr.w3[s];
+        SPICEY_OPAQUE(w0); SPICEY_OPAQUE(w1); SPICEY_OPAQUE(w2); SPICEY_OPAQUE(w3);
+        spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3);
+      }
+    }
+  } else {
+    // resident chunks of this wave that belong to phase p: consecutive slots starting at the cursor;
+    // the slot index is wave-uniform, the records are fetched through the VGPR index register
+    int q = rr.cursor;
+    while (q < RMAX) {
+      const uint32_t pw = rr.phv[q >> 2];
+      const int sp = SPICEY_UNIFORM((int)((pw >> ((q & 3) * 8)) & 0xffu));
+      if (sp != p) break;
+      uint32_t w0 = rr.w0[q], w1 = rr.w1[q], w2 = rr.w2[q], w3 = rr.w3[q];
       SPICEY_OPAQUE(w0); SPICEY_OPAQUE(w1); SPICEY_OPAQUE(w2); SPICEY_OPAQUE(w3);
       spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3);
+      q++;
     }
+    rr.cursor = q;
+  }
   if (!streamed) return;
   const uint32_t sc = Q.st_cnt[p];
   if (sc) {
@@ -487,13 +519,13 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
 // resident capacity (entries >= NSV*T, rows / elements >= T) take the streamed remainder loops.
 // Difference to v1: u[c] holds the capacitor companion CURRENT gc*vPrev (so the right-hand side is a
 // pure +-1 gather, stampCurrentReal.ts:12-13) and the exact vPrev lives in a register.
-template <int K, int RMAX, int NSV>
+template <int K, int RMAX, int NSV, int NEL>
 struct TranPhases2 {
   const SpiceyProg &P;
   const SpiceyRun &R;
   WgCtx<K> &c;
   int T;
-  typedef ResRegs<K, RMAX, NSV> Regs;
+  typedef ResRegs<K, RMAX, NSV, NEL> Regs;
 
   SPICEY_HD double volt16(uint32_t xi, int k) const { return xi == 0xFFFFu ? 0.0 : c.W[(size_t)xi * K + k]; }
   SPICEY_HD double dv16(uint32_t ab, int k) const { return volt16(ab & 0xFFFFu, k) - volt16(ab >> 16, k); }
@@ -502,16 +534,28 @@ struct TranPhases2 {
     for (int s = 0; s < RMAX; s++) {
       const bool have = s < Q.rmax;
       const uint32_t *src = Q.res + ((size_t)(have ? s : 0) * T + tid) * 4;
-      for (int w = 0; w < 4; w++) rr.w[s][w] = have ? src[w] : 0u;
-      rr.ph[s] = have ? SPICEY_UNIFORM(Q.res_phase[(size_t)(tid >> 6) * Q.rmax + s]) : -1;
+      rr.w0[s] = have ? src[0] : 0u; rr.w1[s] = have ? src[1] : 0u; rr.w2[s] = have ? src[2] : 0u; rr.w3[s] = have ? src[3] : 0u;
     }
-    rr.rhs[0] = rr.rhs[1] = 0;
-    if (tid < P.n) { rr.rhs[0] = P.row_desc[(size_t)tid * 2]; rr.rhs[1] = P.row_desc[(size_t)tid * 2 + 1]; }
-    rr.eR = tid < P.nR ? P.R_ab[tid] : 0xFFFFFFFFu;
-    rr.eC = tid < P.nC ? P.C_ab[tid] : 0xFFFFFFFFu;
-    rr.eL = tid < P.nL ? P.L_ab[tid] : 0xFFFFFFFFu;
-    rr.eD = tid < P.nD ? P.D_ab[tid] : 0xFFFFFFFFu;
-    rr.ox = tid < P.nOut ? (P.out_x[tid] < 0 ? 0xFFFFu : (uint32_t)P.out_x[tid]) : 0xFFFFu;
+    for (int s4 = 0; s4 < RMAX / 4; s4++) {
+      uint32_t pk = 0;
+      for (int b = 0; b < 4; b++) {
+        const int s = s4 * 4 + b;
+        const int ph = s < Q.rmax ? Q.res_phase[(size_t)(tid >> 6) * Q.rmax + s] : -1;
+        pk |= (uint32_t)(ph < 0 ? 0xff : (ph & 0xff)) << (8 * b);
+      }
+      rr.phv[s4] = SPICEY_UNIFORM((int)pk);
+    }
+    rr.cursor = 0;
+    for (int j = 0; j < NEL; j++) {
+      const int i = tid + j * T;
+      rr.rhs[j][0] = i < P.n ? P.row_desc[(size_t)i * 2] : 0u;
+      rr.rhs[j][1] = i < P.n ? P.row_desc[(size_t)i * 2 + 1] : 0xFFFFFFFFu;  // 0xFFFFFFFF = not a resident row
+      rr.eR[j] = i < P.nR ? P.R_ab[i] : 0xFFFFFFFFu;
+      rr.eC[j] = i < P.nC ? P.C_ab[i] : 0xFFFFFFFFu;
+      rr.eL[j] = i < P.nL ? P.L_ab[i] : 0xFFFFFFFFu;
+      rr.eD[j] = i < P.nD ? P.D_ab[i] : 0xFFFFFFFFu;
+      rr.ox[j] = i < P.nOut ? (P.out_x[i] < 0 ? 0xFFFFu : (uint32_t)P.out_x[i]) : 0xFFFFu;
+    }
   }
   // after p1_static: static entry values into registers; elements from the state entering the run
   SPICEY_HD void a0_initial(int tid, Regs &rr) const {
@@ -529,7 +573,7 @@ struct TranPhases2 {
     for (int k = 0; k < K; k++) {
       const size_t in = (size_t)c.inst[k];
       const double *g = R.gstat + in * P.nGstat;
-      rr.vprev[k] = tid < P.nC ? R.C_vprev[in * P.nC + tid] : 0.0;
+      for (int j = 0; j < NEL; j++) rr.vprev[j][k] = tid + j * T < P.nC ? R.C_vprev[in * P.nC + tid + j * T] : 0.0;
       SPICEY_NOUNROLL
       for (int i = tid; i < P.nC; i += T) c.u[(size_t)i * K + k] = g[P.nR + i] * R.C_vprev[in * P.nC + i];
       SPICEY_NOUNROLL
@@ -586,8 +630,9 @@ struct TranPhases2 {
   }
 
   // ---- B: matrix = static + dynamic stamps; right-hand side -----------------------------------------
-  SPICEY_HD void b_stamp(int tid, const Regs &rr) const {
+  SPICEY_HD void b_stamp(int tid, Regs &rr) const {
     if (tid == 0) c.flags[0] = 0;
+    rr.cursor = 0;  // a new solve walks the resident slots from the start
     for (int j = 0; j < NSV; j++) {
       const uint32_t e = (uint32_t)(tid + j * T);
       uint32_t dd = rr.dd[j];
@@ -619,13 +664,13 @@ struct TranPhases2 {
         c.W[(size_t)e * K + k] = v;
       }
     }
-    if (tid < P.n) {
-      uint32_t d0 = rr.rhs[0], d1 = rr.rhs[1];
+    for (int j = 0; j < NEL; j++) {
+      uint32_t d0 = rr.rhs[j][0], d1 = rr.rhs[j][1];
       SPICEY_OPAQUE(d0); SPICEY_OPAQUE(d1);
-      if (d1 != 0xFFFFFFFFu) rhs_row((uint32_t)tid, d0, d1);
+      if (d1 != 0xFFFFFFFFu) rhs_row((uint32_t)(tid + j * T), d0, d1);
     }
     SPICEY_NOUNROLL
-    for (int r = tid + T; r < P.n; r += T) {
+    for (int r = tid + NEL * T; r < P.n; r += T) {
       const uint32_t d0 = P.row_desc[(size_t)r * 2], d1 = P.row_desc[(size_t)r * 2 + 1];
       if (d1 != 0xFFFFFFFFu) rhs_row((uint32_t)r, d0, d1);
     }
@@ -685,8 +730,6 @@ struct TranPhases2 {
     const bool last = step == R.steps;
     const int oL = P.nC, oV = P.nC + P.nL, oD = P.nC + P.nL + P.nV;
     const int cR = 0, cC = P.nR, cL = P.nR + P.nC, cV = cL + P.nL, cS = cV + P.nV, cD = cS + P.nS;
-    uint32_t eR = rr.eR, eC = rr.eC, eL = rr.eL, eD = rr.eD, ox = rr.ox;
-    SPICEY_OPAQUE(eR); SPICEY_OPAQUE(eC); SPICEY_OPAQUE(eL); SPICEY_OPAQUE(eD); SPICEY_OPAQUE(ox);
     // The instance loop is kept ROLLED here (one copy of the exp / store code, one instance's working set):
     // unrolled and interleaved it needs ~2x the VGPRs and the register-resident program spills.
     SPICEY_NOUNROLL
@@ -697,29 +740,35 @@ struct TranPhases2 {
       double *ov = R.out_v + (in * (size_t)(R.steps + 1) + (size_t)step) * P.nOut;
       double *oi = R.out_i ? R.out_i + (in * (size_t)(R.steps + 1) + (size_t)step) * P.nCur : nullptr;
       const double *g = R.gstat + in * P.nGstat;
-      if (tid < P.nOut) ov[tid] = volt16(ox, k);
+      for (int j = 0; j < NEL; j++) {  // resident items: element / row / output tid + j T
+        const int i = tid + j * T;
+        uint32_t eR = rr.eR[j], eC = rr.eC[j], eD = rr.eD[j], ox = rr.ox[j];
+        SPICEY_OPAQUE(eR); SPICEY_OPAQUE(eC); SPICEY_OPAQUE(eD); SPICEY_OPAQUE(ox);
+        if (i < P.nOut) ov[i] = volt16(ox, k);
+        if (oi && i < P.nR) oi[cR + i] = dv16(eR, k) * g[i];
+        if (i < P.nC) {
+          double vp = K == 1 ? rr.vprev[j][0] : (k == 0 ? rr.vprev[j][0] : rr.vprev[j][K - 1]);
+          z_cap(i, eC, k, in, g, oi, cC, vp, last);
+          if (K == 1 || k == 0) rr.vprev[j][0] = vp;
+          else rr.vprev[j][K - 1] = vp;
+        }
+        if (i < P.nD) z_dio(i, eD, k, in, oi, cD, oD, last);
+      }
       SPICEY_NOUNROLL
-      for (int i = tid + T; i < P.nOut; i += T) ov[i] = P.out_x[i] < 0 ? 0.0 : c.W[(size_t)P.out_x[i] * K + k];
+      for (int i = tid + NEL * T; i < P.nOut; i += T) ov[i] = P.out_x[i] < 0 ? 0.0 : c.W[(size_t)P.out_x[i] * K + k];
       if (oi) {
-        if (tid < P.nR) oi[cR + tid] = dv16(eR, k) * g[tid];
         SPICEY_NOUNROLL
-        for (int i = tid + T; i < P.nR; i += T) oi[cR + i] = dv16(P.R_ab[i], k) * g[i];
-      }
-      if (tid < P.nC) {
-        double vp = K == 1 ? rr.vprev[0] : (k == 0 ? rr.vprev[0] : rr.vprev[K - 1]);
-        z_cap(tid, eC, k, in, g, oi, cC, vp, last);
-        if (K == 1 || k == 0) rr.vprev[0] = vp;
-        else rr.vprev[K - 1] = vp;
+        for (int i = tid + NEL * T; i < P.nR; i += T) oi[cR + i] = dv16(P.R_ab[i], k) * g[i];
       }
       SPICEY_NOUNROLL
-      for (int i = tid + T; i < P.nC; i += T) {  // beyond the resident capacity: vPrev lives in the state array
+      for (int i = tid + NEL * T; i < P.nC; i += T) {  // beyond the resident capacity: vPrev lives in the state array
         double vp = R.C_vprev[in * P.nC + i];
         z_cap(i, P.C_ab[i], k, in, g, oi, cC, vp, false);
         R.C_vprev[in * P.nC + i] = vp;
       }
       SPICEY_NOUNROLL
       for (int i = tid; i < P.nL; i += T) {
-        const double dv = dv16(i == tid ? eL : P.L_ab[i], k);
+        const double dv = dv16(P.L_ab[i], k);
         const double il = g[P.nR + P.nC + i] * dv + c.u[(size_t)(oL + i) * K + k];
         if (oi) oi[cL + i] = il;
         c.u[(size_t)(oL + i) * K + k] = il;
@@ -739,20 +788,19 @@ struct TranPhases2 {
         c.gd[(size_t)i * K + k] = gs;
         if (last) R.S_ison[in * P.nS + i] = on;
       }
-      if (tid < P.nD) z_dio(tid, eD, k, in, oi, cD, oD, last);
       SPICEY_NOUNROLL
-      for (int i = tid + T; i < P.nD; i += T) z_dio(i, P.D_ab[i], k, in, oi, cD, oD, last);
+      for (int i = tid + NEL * T; i < P.nD; i += T) z_dio(i, P.D_ab[i], k, in, oi, cD, oD, last);
       SPICEY_SCHED_FENCE;
     }
   }
 };
 
-template <int K, int RMAX, int NSV, class Exec>
+template <int K, int RMAX, int NSV, int NEL, class Exec>
 SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, WgCtx<K> &c, int wg) {
   const int T = ex.threads();
   TranPhases<K> ph{P, R, c, T};
-  TranPhases2<K, RMAX, NSV> p2{P, R, c, T};
-  typedef ResRegs<K, RMAX, NSV> Regs;
+  TranPhases2<K, RMAX, NSV, NEL> p2{P, R, c, T};
+  typedef ResRegs<K, RMAX, NSV, NEL> Regs;
   ex.phase(SPICEY_PH_PRO, [&](int tid) {
     if (tid == 0) { c.flags[0] = 0; c.flags[1] = 0; c.flags[2] = -1; }
     ph.p0_gstat(tid);
@@ -779,13 +827,13 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
       for (int p = 0; p < nL; p++) {
         if (p < 64 ? !((active >> p) & 1) : P.ph_cnt[p] == 0) continue;
         ex.phase(SPICEY_PH_U0 + (p < 31 ? p : 31), [&](int tid) {
-          spicey_uk_phase<K, RMAX, NSV, false>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
+          spicey_uk_phase<K, RMAX, NSV, NEL, false>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
         });
       }
       for (int p = nL; p < 2 * nL; p++) {
         const int l = 2 * nL - 1 - p;
         ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) {
-          spicey_uk_phase<K, RMAX, NSV, true>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
+          spicey_uk_phase<K, RMAX, NSV, NEL, true>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
         });
       }
       if (c.flags[1]) { code = 1; err_step = step; err_iter = iter; break; }

@@ -132,7 +132,8 @@ class Handle:
         buf = (C.c_uint64 * 72)()
         self.L.spicey_debug_phase_cycles(self.h, buf, 72)
         a = list(buf)
-        return {"prologue": a[0], "B": a[1], "S": a[2], "A": a[3], "Z": a[4], "U": a[8:40], "K": a[40:72]}
+        return {"prologue": a[0], "B": a[1], "S": a[2], "A": a[3], "Z": a[4], "run_cycles": a[5], "run_wall_ticks_100MHz": a[6],
+                "U": a[8:40], "K": a[40:72]}
 
     def state(self) -> dict:
         f = self.flat

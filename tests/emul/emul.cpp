@@ -54,9 +54,10 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
       spicey_build_resident(hp, T, rmax, hr);
       SpiceyResident Q = hr.bind(hr.blob.data());
       // NSV = 2 resident entries per thread: small on purpose so that tests also cover the streamed remainder
-      std::vector<ResRegs<K, 16, 2>> regs(T);
+      // NEL = 2 resident elements / rows per thread: with the small T the tests use, the remainder loops run too
+      std::vector<ResRegs<K, 16, 2, 2>> regs(T);
       ex.rr = &regs;
-      spicey_tran_run_v2<K, 16, 2>(ex, P, Q, R, c, g);
+      spicey_tran_run_v2<K, 16, 2, 2>(ex, P, Q, R, c, g);
     }
   }
 }
