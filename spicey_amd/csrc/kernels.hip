@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(1024) spicey_tran_kernel(SpiceyProg P, SpiceyR
     c.ison = (int32_t *)(c.gd + nG);
     c.flags = (int32_t *)smem;
   }
+  c.tail = nullptr;
 #pragma unroll
   for (int k = 0; k < K; k++) {
     const int in = wg * K + k;
@@ -72,6 +73,25 @@ struct GpuExecV2 {
   template <class R2>
   __device__ __forceinline__ R2 &regs(int) {
     return rr;
+  }
+  // tail: wave 0 runs `nlev` dependent levels back to back.  LDS operations of one wave execute in order, so a
+  // level's ds_writes are seen by the next level's ds_reads without any workgroup barrier; the fences only stop
+  // the compiler from moving or caching LDS accesses across levels.
+  template <class F>
+  __device__ __forceinline__ void tail_phase(int tag, int nlev, F f) {
+    long long t0 = 0;
+    if (prof && threadIdx.x == 0) t0 = clock64();
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    if (tid < 64) {
+      for (int l = 0; l < nlev; l++) {
+        f(tid, l);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    if (prof && threadIdx.x == 0) atomicAdd(&prof[tag], (unsigned long long)(clock64() - t0));
   }
   template <class F>
   __device__ __forceinline__ void phase(int tag, F f) {
@@ -106,7 +126,11 @@ __global__ void __launch_bounds__(MAXT, MINW) spicey_tran_kernel_v2(SpiceyProg P
   }
   GpuExecV2<ResRegs<K, RMAX, NSV, NEL>> ex;
   // profiling accumulators live in LDS behind the flags (576 B, reserved by spicey_lds_bytes)
-  unsigned long long *lprof = (unsigned long long *)(((uintptr_t)(c.flags + 4) + 7) & ~(uintptr_t)7);
+  // (offsets from `smem`, no integer casts: the pointers must keep their LDS address space, or every access
+  // becomes a flat_load)
+  const size_t off_prof = ((nW + nU + nG) * sizeof(double) + ((size_t)P.nS * K + 4) * sizeof(int32_t) + 15) & ~(size_t)15;
+  unsigned long long *lprof = (unsigned long long *)(smem + off_prof);
+  c.tail = (uint32_t *)(smem + off_prof + SPICEY_PH_SLOTS * sizeof(unsigned long long));
   ex.prof = R.prof ? lprof : nullptr;
   long long c0 = 0, w0 = 0;
   if (R.prof) {
@@ -150,10 +174,11 @@ hipError_t launch_t(const SpiceyProg &P, const SpiceyRun &R, int grid, int threa
 
 }  // namespace
 
-size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds) {
+size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds, int tail_n) {
   if (!lds) return 64;
   size_t b = ((size_t)P.nW + P.nU + P.nGdyn) * K * sizeof(double) + ((size_t)P.nS * K + 4) * sizeof(int32_t);
   b = ((b + 15) & ~size_t(15)) + SPICEY_PH_SLOTS * sizeof(unsigned long long);  // + profiling accumulators
+  b = ((b + 15) & ~size_t(15)) + (size_t)tail_n * 64 * 16;                          // + tail task records
   return (b + 15) & ~size_t(15);
 }
 
@@ -162,7 +187,7 @@ size_t spicey_gw_doubles_per_wg(const SpiceyProg &P, int K) {
 }
 
 hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bool lds, int grid, int threads, hipStream_t st) {
-  const size_t bytes = spicey_lds_bytes(P, K, lds);
+  const size_t bytes = spicey_lds_bytes(P, K, lds, 0);
   if (lds) {
     switch (K) {
       case 1: return launch_t<1, true>(P, R, grid, threads, bytes, st);
@@ -193,7 +218,7 @@ int spicey_v2_max_threads(int K) { return K == 1 ? 1024 : 256; }
 
 hipError_t spicey_launch_tran_v2(const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, int K, int grid, int threads,
                                  hipStream_t st) {
-  const size_t bytes = spicey_lds_bytes(P, K, true);
+  const size_t bytes = spicey_lds_bytes(P, K, true, Q.tail_n);
   if (threads <= 256) {
     switch (K) {
       case 1: return launch_v2_t<1, 32, 12, 4, 256, 1>(P, Q, R, grid, threads, bytes, st);

@@ -125,6 +125,11 @@ struct SpiceyResident {
   const uint32_t *st_cnt;     // [2 nLevels]
   int32_t rmax;
   int32_t T;
+  // "tail": the run of consecutive phases [tail_first, tail_first + tail_n) at the top of the elimination tree
+  // that have <= 64 tasks each.  ONE wave executes them back to back inside a single barrier phase (records in
+  // LDS), which removes tail_n - 1 workgroup barriers and phase dispatches from every solve.
+  int32_t tail_first;
+  int32_t tail_n;
 };
 
 // Per-run, per-instance data (device pointers; instance-major arrays)

@@ -867,7 +867,7 @@ SpiceyProg HostProgram::bind(const void *base) const {
 // ---------------------------------------------------------------------------------------------
 // Resident layout: chunks of 64 lanes; chunk c lives in (wave c % nWaves, slot c / nWaves), so the
 // chunks of one phase spread over the waves.  Smallest phases first (they are pure latency).
-void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident &out) {
+void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident &out, int max_tail) {
   out = HostResident();
   out.rmax = rmax; out.T = T;
   const int nPh = (int)hp.ph_cnt.size();
@@ -876,6 +876,15 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
   out.res_phase.assign((size_t)nWaves * rmax, -1);
   out.st_first.assign(std::max(nPh, 1), 0u);
   out.st_cnt.assign(std::max(nPh, 1), 0u);
+  if (hp.hdr.has16 && nPh <= 254 && max_tail > 1) {
+    // tail: longest run of <= 64-task phases around the factor -> backward turn (phase nLevels-1 | nLevels)
+    const int nL = hp.hdr.nLevels;
+    int a = nL, b = nL;  // [a, b)
+    while (a > 0 && hp.ph_cnt[a - 1] <= 64 && b - (a - 1) <= max_tail) a--;
+    while (b < nPh && hp.ph_cnt[b] <= 64 && (b + 1) - a <= max_tail) b++;
+    while (a < b && hp.ph_cnt[a] == 0) a++;  // skip empty leading phases (the top factor level has no tasks)
+    if (b - a >= 3) { out.tail_first = a; out.tail_n = b - a; }
+  }
   if (hp.hdr.has16 && nPh <= 254) {
     // 1. which phases become resident: smallest first (they are pure latency) while chunks remain;
     //    chunk c of the running count goes to wave c % nWaves, so a phase spreads over the waves
@@ -889,6 +898,7 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
     for (int p : order) {
       const int cnt = (int)hp.ph_cnt[p];
       if (cnt == 0) continue;
+      if (p >= out.tail_first && p < out.tail_first + out.tail_n) continue;  // lives in the LDS tail table
       const int need = (cnt + 63) / 64;
       bool fits = true;
       {
@@ -946,5 +956,7 @@ SpiceyResident HostResident::bind(const void *base) const {
   r.st_cnt = (const uint32_t *)(b + offsets[3]);
   r.rmax = rmax;
   r.T = T;
+  r.tail_first = tail_first;
+  r.tail_n = tail_n;
   return r;
 }

@@ -50,14 +50,14 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
 struct HostResident {
   std::vector<uint32_t> res, st_first, st_cnt;
   std::vector<int32_t> res_phase;
-  int rmax = 0, T = 0;
+  int rmax = 0, T = 0, tail_first = 0, tail_n = 0;
   int64_t resident_tasks = 0, streamed_tasks = 0;
   std::vector<uint8_t> blob;
   std::vector<size_t> offsets;
   void pack();
   SpiceyResident bind(const void *base) const;
 };
-void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident &out);
+void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident &out, int max_tail = 0);
 
 // SURVEY.md §8(d) algorithmic bytes per solve.
 int64_t spicey_algorithmic_bytes(const SpiceyDesc *d, int32_t nnzA, int32_t nnzLU);

@@ -33,6 +33,9 @@
 // Keeps a register-resident packed word packed: without this hipcc hoists the field decode (8+ VGPRs and
 // a mask pair per record) out of the time loop and spills.
 #define SPICEY_OPAQUE(x) asm volatile("" : "+v"(x))
+// Same for wave-uniform values (instance index): per-instance base pointers derived from it are then formed
+// inside the phase that needs them instead of living in (spilled) SGPRs across the whole time loop.
+#define SPICEY_OPAQUE_S(x) asm volatile("" : "+s"(x))
 #define SPICEY_NOUNROLL _Pragma("unroll 1")  // thread-strided loops run 1-2 trips: unrolling only costs VGPRs
 #define SPICEY_SCHED_FENCE __builtin_amdgcn_sched_barrier(0)  // keep the K instances' code from being interleaved
 #else
@@ -40,6 +43,7 @@
 #define SPICEY_SCHED_FENCE
 #define SPICEY_UNIFORM(x) (x)
 #define SPICEY_OPAQUE(x) (void)(x)
+#define SPICEY_OPAQUE_S(x) (void)(x)
 #endif
 
 // phase tags (profiling slots, SpiceyRun::prof)
@@ -59,6 +63,7 @@ struct WgCtx {
   double *gd;    // [nGdyn][K] switch conductances | diode gd
   int32_t *ison; // [nS][K]
   int32_t *flags;  // [0] switched, [1] singular code, [2] singular inst
+  uint32_t *tail;  // [tail_n][64][4] task records of the tail phases (v2), or null
   int32_t inst[K];
   int32_t valid[K];
 };
@@ -257,7 +262,7 @@ struct TranPhases {
         const uint32_t di = P.upd_pairs[off + (j * 3 + 1) * 64];
         const uint32_t ui = P.upd_pairs[off + (j * 3 + 2) * 64];
         for (int k = 0; k < K; k++)
-          acc[k] -= (c.W[(size_t)li * K + k] * c.W[(size_t)di * K + k]) * c.W[(size_t)ui * K + k];
+          acc[k] = fma(-(c.W[(size_t)li * K + k] * c.W[(size_t)di * K + k]), c.W[(size_t)ui * K + k], acc[k]);
       }
       if (tgt & SPICEY_TGT_RECIP) {
         for (int k = 0; k < K; k++) {
@@ -283,7 +288,7 @@ struct TranPhases {
       for (uint32_t j = 0; j < cnt; j++) {
         const uint32_t ui = P.bk_pairs[off + (j * 2 + 0) * 64];
         const uint32_t xb = P.bk_pairs[off + (j * 2 + 1) * 64];
-        for (int k = 0; k < K; k++) acc[k] -= c.W[(size_t)ui * K + k] * c.W[(size_t)xb * K + k];
+        for (int k = 0; k < K; k++) acc[k] = fma(-c.W[(size_t)ui * K + k], c.W[(size_t)xb * K + k], acc[k]);
       }
       for (int k = 0; k < K; k++) c.W[(size_t)xi * K + k] = acc[k] * c.W[(size_t)di * K + k];
     }
@@ -418,47 +423,63 @@ struct ResRegs {
   double vprev[NEL][K]; // vPrev of capacitors tid + j T (simulateTRAN.ts:221-225), exact
 };
 
+// One task.  For the common inline case (<= 2 products) ALL operands are fetched up front — unused index fields
+// are 0, a valid address — and the unused products are masked by selects: one LDS round trip per task instead of
+// one per product (the dependent ds_read -> wait -> fma chains dominated the small phases).
 template <int K, bool KTASK>
 SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
   const uint32_t meta = w0 >> 16;
   if (!(meta & (SPICEY_R16_VALID << 8))) return;
   const uint32_t tgt = w0 & 0xffffu, cnt = meta & 0xffu;
   double acc[K];
-  for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)tgt * K + k];
   if (KTASK) {
     const uint32_t d = w1 & 0xffffu;
     if (cnt <= 2) {
-      if (cnt >= 1) {
-        const uint32_t u0 = w1 >> 16, x0 = w2 & 0xffffu;
-        for (int k = 0; k < K; k++) acc[k] -= c.W[(size_t)u0 * K + k] * c.W[(size_t)x0 * K + k];
+      const uint32_t u0 = w1 >> 16, x0 = w2 & 0xffffu, u1 = w2 >> 16, x1 = w3 & 0xffffu;
+      double a0[K], b0[K], a1[K], b1[K], dv[K];
+      for (int k = 0; k < K; k++) {
+        acc[k] = c.W[(size_t)tgt * K + k];
+        a0[k] = c.W[(size_t)u0 * K + k]; b0[k] = c.W[(size_t)x0 * K + k];
+        a1[k] = c.W[(size_t)u1 * K + k]; b1[k] = c.W[(size_t)x1 * K + k];
+        dv[k] = c.W[(size_t)d * K + k];
       }
-      if (cnt == 2) {
-        const uint32_t u1 = w2 >> 16, x1 = w3 & 0xffffu;
-        for (int k = 0; k < K; k++) acc[k] -= c.W[(size_t)u1 * K + k] * c.W[(size_t)x1 * K + k];
+      for (int k = 0; k < K; k++) {  // explicit fma: the same rounding in every interpreter and geometry
+        const double s0 = fma(-a0[k], b0[k], acc[k]);
+        acc[k] = cnt >= 1 ? s0 : acc[k];
+        const double s1 = fma(-a1[k], b1[k], acc[k]);
+        acc[k] = (cnt == 2 ? s1 : acc[k]) * dv[k];
       }
     } else {
+      for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)tgt * K + k];
       const uint16_t *o = ovf + w3;
       for (uint32_t j = 0; j < cnt; j++) {
         const uint32_t u = o[2 * j], x = o[2 * j + 1];
-        for (int k = 0; k < K; k++) acc[k] -= c.W[(size_t)u * K + k] * c.W[(size_t)x * K + k];
+        for (int k = 0; k < K; k++) acc[k] = fma(-c.W[(size_t)u * K + k], c.W[(size_t)x * K + k], acc[k]);
       }
+      for (int k = 0; k < K; k++) acc[k] *= c.W[(size_t)d * K + k];
     }
-    for (int k = 0; k < K; k++) c.W[(size_t)tgt * K + k] = acc[k] * c.W[(size_t)d * K + k];
+    for (int k = 0; k < K; k++) c.W[(size_t)tgt * K + k] = acc[k];
   } else {
     if (cnt <= 2) {
-      if (cnt >= 1) {
-        const uint32_t l0 = w1 & 0xffffu, d0 = w1 >> 16, u0 = w2 & 0xffffu;
-        for (int k = 0; k < K; k++) acc[k] -= (c.W[(size_t)l0 * K + k] * c.W[(size_t)d0 * K + k]) * c.W[(size_t)u0 * K + k];
+      const uint32_t l0 = w1 & 0xffffu, d0 = w1 >> 16, u0 = w2 & 0xffffu, l1 = w2 >> 16, d1 = w3 & 0xffffu, u1 = w3 >> 16;
+      double p0[K], q0[K], r0[K], p1[K], q1[K], r1[K];
+      for (int k = 0; k < K; k++) {
+        acc[k] = c.W[(size_t)tgt * K + k];
+        p0[k] = c.W[(size_t)l0 * K + k]; q0[k] = c.W[(size_t)d0 * K + k]; r0[k] = c.W[(size_t)u0 * K + k];
+        p1[k] = c.W[(size_t)l1 * K + k]; q1[k] = c.W[(size_t)d1 * K + k]; r1[k] = c.W[(size_t)u1 * K + k];
       }
-      if (cnt == 2) {
-        const uint32_t l1 = w2 >> 16, d1 = w3 & 0xffffu, u1 = w3 >> 16;
-        for (int k = 0; k < K; k++) acc[k] -= (c.W[(size_t)l1 * K + k] * c.W[(size_t)d1 * K + k]) * c.W[(size_t)u1 * K + k];
+      for (int k = 0; k < K; k++) {
+        const double s0 = fma(-(p0[k] * q0[k]), r0[k], acc[k]);
+        acc[k] = cnt >= 1 ? s0 : acc[k];
+        const double s1 = fma(-(p1[k] * q1[k]), r1[k], acc[k]);
+        acc[k] = cnt == 2 ? s1 : acc[k];
       }
     } else {
+      for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)tgt * K + k];
       const uint16_t *o = ovf + w3;
       for (uint32_t j = 0; j < cnt; j++) {
         const uint32_t l = o[3 * j], d = o[3 * j + 1], u = o[3 * j + 2];
-        for (int k = 0; k < K; k++) acc[k] -= (c.W[(size_t)l * K + k] * c.W[(size_t)d * K + k]) * c.W[(size_t)u * K + k];
+        for (int k = 0; k < K; k++) acc[k] = fma(-(c.W[(size_t)l * K + k] * c.W[(size_t)d * K + k]), c.W[(size_t)u * K + k], acc[k]);
       }
     }
     if (meta & (SPICEY_R16_RECIP << 8)) {
@@ -745,14 +766,18 @@ struct TranPhases2 {
         uint32_t eR = rr.eR[j], eC = rr.eC[j], eD = rr.eD[j], ox = rr.ox[j];
         SPICEY_OPAQUE(eR); SPICEY_OPAQUE(eC); SPICEY_OPAQUE(eD); SPICEY_OPAQUE(ox);
         if (i < P.nOut) ov[i] = volt16(ox, k);
+        SPICEY_SCHED_FENCE;
         if (oi && i < P.nR) oi[cR + i] = dv16(eR, k) * g[i];
+        SPICEY_SCHED_FENCE;
         if (i < P.nC) {
           double vp = K == 1 ? rr.vprev[j][0] : (k == 0 ? rr.vprev[j][0] : rr.vprev[j][K - 1]);
           z_cap(i, eC, k, in, g, oi, cC, vp, last);
           if (K == 1 || k == 0) rr.vprev[j][0] = vp;
           else rr.vprev[j][K - 1] = vp;
         }
+        SPICEY_SCHED_FENCE;
         if (i < P.nD) z_dio(i, eD, k, in, oi, cD, oD, last);
+        SPICEY_SCHED_FENCE;
       }
       SPICEY_NOUNROLL
       for (int i = tid + NEL * T; i < P.nOut; i += T) ov[i] = P.out_x[i] < 0 ? 0.0 : c.W[(size_t)P.out_x[i] * K + k];
@@ -805,6 +830,12 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
     if (tid == 0) { c.flags[0] = 0; c.flags[1] = 0; c.flags[2] = -1; }
     ph.p0_gstat(tid);
     p2.load_resident(tid, Q, ex.template regs<Regs>(tid));
+    for (int i = tid; i < Q.tail_n * 64; i += T) {  // tail records -> LDS (invalid record = all zero)
+      const int p = Q.tail_first + (i >> 6), lane = i & 63;
+      const bool have = (uint32_t)lane < P.ph_cnt[p];
+      const uint32_t *src = P.rec16 + ((size_t)P.ph_first[p] + (have ? lane : 0)) * 4;
+      for (int w = 0; w < 4; w++) c.tail[(size_t)i * 4 + w] = have ? src[w] : 0u;
+    }
   });
   ex.phase(SPICEY_PH_PRO, [&](int tid) { ph.p1_static(tid); });
   ex.phase(SPICEY_PH_PRO, [&](int tid) { p2.a0_initial(tid, ex.template regs<Regs>(tid)); });
@@ -820,17 +851,27 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
     if (SPICEY_UNIFORM((int)P.ph_cnt[p]) != 0) active |= 1ull << p;
     if (SPICEY_UNIFORM((int)Q.st_cnt[p]) != 0) smask |= 1ull << p;
   }
+  const int u_end = Q.tail_n > 0 ? Q.tail_first : nL;
+  const int k_begin = Q.tail_n > 0 ? Q.tail_first + Q.tail_n : nL;
   for (int64_t step = 0; step <= R.steps && code == 0; step++) {
     int iter = 0;
     for (;;) {
       ex.phase(SPICEY_PH_B, [&](int tid) { p2.b_stamp(tid, ex.template regs<Regs>(tid)); });
-      for (int p = 0; p < nL; p++) {
+      // factor levels [0, u_end) | tail [u_end, k_begin) by one wave | backward levels [k_begin, 2 nL)
+      for (int p = 0; p < u_end; p++) {
         if (p < 64 ? !((active >> p) & 1) : P.ph_cnt[p] == 0) continue;
-        ex.phase(SPICEY_PH_U0 + (p < 31 ? p : 31), [&](int tid) {
+        ex.phase(SPICEY_PH_U0 + (p < 30 ? p : 30), [&](int tid) {
           spicey_uk_phase<K, RMAX, NSV, NEL, false>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
         });
       }
-      for (int p = nL; p < 2 * nL; p++) {
+      if (k_begin > u_end) {
+        ex.tail_phase(SPICEY_PH_U0 + 31, k_begin - u_end, [&](int tid, int lvl) {
+          const uint32_t *r = c.tail + ((size_t)lvl * 64 + tid) * 4;
+          if (u_end + lvl < nL) spicey_exec_rec16<K, false>(c, P.ovf16, r[0], r[1], r[2], r[3]);
+          else spicey_exec_rec16<K, true>(c, P.ovf16, r[0], r[1], r[2], r[3]);
+        });
+      }
+      for (int p = k_begin; p < 2 * nL; p++) {
         const int l = 2 * nL - 1 - p;
         ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) {
           spicey_uk_phase<K, RMAX, NSV, NEL, true>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);

@@ -24,6 +24,16 @@ struct SeqExec {
   Regs &regs(int tid) {
     return (*static_cast<std::vector<Regs> *>(rr))[tid];
   }
+  // one wave, `nlev` dependent levels in lockstep: every lane finishes level l before any lane starts l + 1
+  template <class F>
+  void tail_phase(int, int nlev, F f) {
+    for (int l = 0; l < nlev; l++) {
+      if (!reverse)
+        for (int t = 0; t < 64; t++) f(t, l);
+      else
+        for (int t = 63; t >= 0; t--) f(t, l);
+    }
+  }
   template <class F>
   void phase(int, F f) {
     if (!reverse)
@@ -40,7 +50,7 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
   std::vector<int32_t> ison((size_t)(P.nS + 1) * K), flags(4);
   for (int g = 0; g < ngroups; g++) {
     WgCtx<K> c;
-    c.W = W.data(); c.u = u.data(); c.gd = gd.data(); c.ison = ison.data(); c.flags = flags.data();
+    c.W = W.data(); c.u = u.data(); c.gd = gd.data(); c.ison = ison.data(); c.flags = flags.data(); c.tail = nullptr;
     for (int k = 0; k < K; k++) {
       int in = g * K + k;
       c.valid[k] = in < R.n_inst;
@@ -51,8 +61,10 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
       spicey_tran_run<K>(ex, P, R, c, g);
     } else {
       HostResident hr;
-      spicey_build_resident(hp, T, rmax, hr);
+      spicey_build_resident(hp, T, rmax, hr, 24);
       SpiceyResident Q = hr.bind(hr.blob.data());
+      std::vector<uint32_t> tail((size_t)(hr.tail_n + 1) * 64 * 4);
+      c.tail = tail.data();
       // NSV = 2 resident entries per thread: small on purpose so that tests also cover the streamed remainder
       // NEL = 2 resident elements / rows per thread: with the small T the tests use, the remainder loops run too
       std::vector<ResRegs<K, 16, 2, 2>> regs(T);

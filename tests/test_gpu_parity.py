@@ -186,7 +186,7 @@ def test_determinism_across_handles_and_geometries():
     flat, dt, steps, src = synth.chain_batch("rc_ladder", 1000, [1], tran=".tran 1e-6 1e-3")
     f2, dt2, st2, src2 = synth.chain_batch("diode_chain", 40, range(1, 8), tran=".tran 1e-6 3e-5")
     first = None
-    for T, interp in [(0, 0), (256, 2), (512, 2), (1024, 2), (256, 2), (512, 1), (0, 0)]:
+    for T, interp in [(0, 0), (256, 2), (512, 2), (1024, 2), (256, 2), (512, 1), (256, 1), (0, 0)]:
         HipBackend(threads=64).run(f2, st2, dt2, src2)  # something different in between
         r = HipBackend(threads=T, interpreter=interp).run(flat, steps, dt, src)
         assert r["status"] == 0
