@@ -38,7 +38,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def pmc_traffic(solves_per_launch):
+def pmc_traffic(solves_per_launch, workload_key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json: separate
     FETCH_SIZE / WRITE_SIZE runs of this same command, corrected as MI355X_MICROARCH.md prescribes).  Counters
     cannot be read from inside the timed run, so the value is only reported when the committed measurement
@@ -48,7 +48,7 @@ def pmc_traffic(solves_per_launch):
         try:
             with open(f) as fh:
                 t = json.load(fh)
-            if int(t["solves_per_launch"]) == int(solves_per_launch):
+            if int(t["solves_per_launch"]) == int(solves_per_launch) and t.get("workload_key") == workload_key:
                 return float(t["traffic_bytes_per_launch"]), os.path.basename(f)
         except (OSError, KeyError, ValueError):
             pass
@@ -166,7 +166,7 @@ def main():
         solves_per_launch = solves_rank / args.steps
         algo = info["algorithmic_bytes_solve"]
         achieved = algo * solves_per_launch / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(solves_per_launch)
+        traffic, traffic_src = pmc_traffic(solves_per_launch, f"{args.workload}:{n}:{tsteps}:{B}:{int(not args.no_currents)}")
         rec = {
             "metric": "Newton-LU timestep solves/sec, 1000-node netlist",
             "value": total_solves / el,

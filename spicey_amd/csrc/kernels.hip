@@ -178,7 +178,7 @@ size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds, int tail_n) {
   if (!lds) return 64;
   size_t b = ((size_t)P.nW + P.nU + P.nGdyn) * K * sizeof(double) + ((size_t)P.nS * K + 4) * sizeof(int32_t);
   b = ((b + 15) & ~size_t(15)) + SPICEY_PH_SLOTS * sizeof(unsigned long long);  // + profiling accumulators
-  b = ((b + 15) & ~size_t(15)) + (size_t)tail_n * 64 * 16;                          // + tail task records
+  b = ((b + 15) & ~size_t(15)) + (size_t)tail_n * 64 * 32;                          // + pre-decoded tail task records
   return (b + 15) & ~size_t(15);
 }
 

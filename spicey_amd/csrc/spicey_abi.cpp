@@ -173,9 +173,9 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   h->grid = (h->n_inst + K - 1) / K;
   h->lds_bytes = spicey_lds_bytes(P, K, h->lds);
   if (h->interp == 2) {
-    // tail levels go to LDS: as many as fit beside the workspace (1 KB each), at most 24
+    // tail levels go to LDS: as many as fit beside the workspace (2 KB each), at most 24
     const size_t base = spicey_lds_bytes(P, K, true, 0);
-    int max_tail = (int)std::min<size_t>(24, base < SPICEY_LDS_MAX ? (SPICEY_LDS_MAX - base) / 1024 : 0);
+    int max_tail = (int)std::min<size_t>(24, base < SPICEY_LDS_MAX ? (SPICEY_LDS_MAX - base) / 2048 : 0);
     if (h->opt.reserved[0] == 1) max_tail = 0;  // diagnostics: disable the tail merge
     spicey_build_resident(h->hp, h->T, spicey_v2_rmax(h->T), h->hres, max_tail);
     h->lds_bytes = spicey_lds_bytes(P, K, true, h->hres.tail_n);

@@ -63,13 +63,20 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
       HostResident hr;
       spicey_build_resident(hp, T, rmax, hr, 24);
       SpiceyResident Q = hr.bind(hr.blob.data());
-      std::vector<uint32_t> tail((size_t)(hr.tail_n + 1) * 64 * 4);
+      std::vector<uint32_t> tail((size_t)(hr.tail_n + 1) * 64 * 8);
       c.tail = tail.data();
       // NSV = 2 resident entries per thread: small on purpose so that tests also cover the streamed remainder
-      // NEL = 2 resident elements / rows per thread: with the small T the tests use, the remainder loops run too
-      std::vector<ResRegs<K, 16, 2, 2>> regs(T);
-      ex.rr = &regs;
-      spicey_tran_run_v2<K, 16, 2, 2>(ex, P, Q, R, c, g);
+      // NEL = 2 resident elements / rows per thread: with the small T the tests use, the remainder loops run too.
+      // rmax <= 8 takes the static-dispatch code path (RMAX = 8), larger the indexed-register path (RMAX = 16).
+      if (rmax <= 8) {
+        std::vector<ResRegs<K, 8, 2, 2>> regs(T);
+        ex.rr = &regs;
+        spicey_tran_run_v2<K, 8, 2, 2>(ex, P, Q, R, c, g);
+      } else {
+        std::vector<ResRegs<K, 16, 2, 2>> regs(T);
+        ex.rr = &regs;
+        spicey_tran_run_v2<K, 16, 2, 2>(ex, P, Q, R, c, g);
+      }
     }
   }
 }
@@ -112,7 +119,7 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
   std::vector<unsigned long long> solves(ngroups);
   R.status = status.data(); R.solves = solves.data();
   if (T <= 0 || (T & 63)) return SPICEY_ERR_BAD_DESC;
-  if (rmax > 16 || (rmax >= 0 && !P.has16)) return SPICEY_ERR_BAD_DESC;
+  if (rmax > 16 || (rmax >= 0 && (!P.has16 || K > 2))) return SPICEY_ERR_BAD_DESC;  // v2 supports K <= 2
   switch (K) {
     case 1: run_groups<1>(hp, P, R, T, reverse != 0, rmax); break;
     case 2: run_groups<2>(hp, P, R, T, reverse != 0, rmax); break;
