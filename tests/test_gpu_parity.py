@@ -178,6 +178,60 @@ def test_full_size_properties():
         assert np.array_equal(d["out_v"][k], a["out_v"][0])
 
 
+@pytest.mark.parametrize("kind,n", [("rc_ladder", 1500), ("diode_chain", 1400)])
+def test_beyond_resident_capacity(kind, n, oracle_backend):
+    """More unknowns than threads: part of the program is streamed from L2 and the per-thread remainder loops of
+    the B / Z phases run (rows, elements and entries beyond what one thread keeps in registers)."""
+    from spicey_amd.lib import HipBackend
+    flat, dt, steps, src = synth.chain_batch(kind, n, [3], tran=".tran 1e-6 2.5e-5")
+    be = HipBackend()
+    got = be.run(flat, steps, dt, src)
+    assert got["status"] == 0 and be.info["interpreter"] == 2 and be.info["n_var"] > be.info["threads"]
+    if kind == "rc_ladder":
+        assert be.info["streamed_tasks"] > 0
+    ref = oracle_backend.run(flat, steps, dt, src)
+    assert tol_ratio(got["out_v"], ref["out_v"]).max() <= 1.0
+    assert tol_ratio(got["out_i"], ref["out_i"]).max() <= 1.0
+    for k in ("C_vprev", "D_vdprev"):
+        assert tol_ratio(got["state"][k], ref["state"][k]).max() <= 1.0
+
+
+def test_large_instance_global_workspace(oracle_backend):
+    """rcd_mesh(34x34): L+U no longer fits the 160 KB LDS -> 32-bit task lists on a global (L2) workspace."""
+    from spicey_amd.lib import HipBackend
+    ckt = parseNetlist(synth.rcd_mesh(34, seed=11, tran=".tran 1e-6 8e-6"))
+    dt, steps = abi.computeEffectiveTimeStep(1e-6, 8e-6)
+    flat = abi.flatten(ckt)
+    src = abi.source_table(ckt, dt, steps)
+    be = HipBackend()
+    got = be.run(flat, steps, dt, src)
+    assert got["status"] == 0 and be.info["lds_bytes"] == 0 and be.info["interpreter"] == 1
+    ref = oracle_backend.run(flat, steps, dt, src)
+    assert tol_ratio(got["out_v"], ref["out_v"]).max() <= 1.0
+    assert tol_ratio(got["out_i"], ref["out_i"]).max() <= 1.0
+
+
+def test_degenerate_shapes(oracle_backend):
+    """No capacitors / no diodes / single unknown / odd instance count with two instances per workgroup."""
+    from spicey_amd.lib import HipBackend
+    for text in ("* divider\nV1 a 0 dc 3\nR1 a b 1k\nR2 b 0 2k\n.tran 1u 4u\n.end\n",
+                 "* one node\nV1 a 0 PULSE(0 1 0 1u 1u 2u 5u)\n.tran 1u 6u\n.end\n"):
+        ckt = parseNetlist(text)
+        tr = ckt.analyses["tran"]
+        dt, steps = abi.computeEffectiveTimeStep(tr["dt"], tr["tstop"])
+        flat = abi.flatten(ckt)
+        src = abi.source_table(ckt, dt, steps)
+        ref = oracle_backend.run(flat, steps, dt, src)
+        for interp in (1, 2):
+            got = HipBackend(interpreter=interp).run(flat, steps, dt, src)
+            assert got["status"] == 0
+            assert tol_ratio(got["out_v"], ref["out_v"]).max() <= 1.0 and tol_ratio(got["out_i"], ref["out_i"]).max() <= 1.0
+    flat, dt, steps, src = synth.chain_batch("diode_chain", 30, range(1, 4), tran=".tran 1e-6 1e-5")  # 3 instances, K = 2
+    ref = oracle_backend.run(flat, steps, dt, src)
+    got = HipBackend(inst_per_wg=2).run(flat, steps, dt, src)
+    assert got["status"] == 0 and tol_ratio(got["out_v"], ref["out_v"]).max() <= 1.0
+
+
 def test_determinism_across_handles_and_geometries():
     """Regression: results must not depend on what ran before (stale scratch / registers) nor on the workgroup
     geometry.  The gather-form program has a fixed summation order, so outputs are bit-identical across thread

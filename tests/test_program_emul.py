@@ -98,6 +98,28 @@ def test_program_batched_instances(K, T, oracle_backend):
     assert be.solves == 7 * (steps + 1)
 
 
+@pytest.mark.parametrize("name", SMALL_GOLDENS + ["mesh20_30"])
+def test_register_resident_interpreter_matches_v1_bitwise(name):
+    """v2 (16-bit records in 'registers', tail levels, cursor / static dispatch, remainder loops) against the v1
+    interpreter: the gather-form program has one summation order, so every variant is bit-identical."""
+    flat, steps, dt, src = _inputs(name)
+    v1 = EmulBackend(1, 128).run(flat, steps, dt, src)
+    for T, rev, rmax in ((128, False, 8), (64, True, 2), (256, False, 0), (64, False, 16)):
+        got = EmulBackend(1, T, rev, rmax).run(flat, steps, dt, src)
+        assert got["status"] == v1["status"] == 0
+        assert np.array_equal(got["out_v"], v1["out_v"]) and np.array_equal(got["iters"], v1["iters"])
+        a, b = got["out_i"], v1["out_i"]
+        assert np.array_equal(np.isfinite(a), np.isfinite(b)) and np.array_equal(a[np.isfinite(a)], b[np.isfinite(b)])
+
+
+def test_register_resident_batched_two_per_workgroup(oracle_backend):
+    flat, dt, steps, src = synth.chain_batch("diode_chain", 40, range(1, 8), tran=".tran 1e-6 3e-5")
+    ref = oracle_backend.run(flat, steps, dt, src)
+    for T, rmax in ((64, 4), (256, 8), (128, 0)):
+        got = EmulBackend(2, T, False, rmax).run(flat, steps, dt, src)
+        assert got["status"] == 0 and ratio(got["out_v"], ref["out_v"]).max() <= 1.0 and ratio(got["out_i"], ref["out_i"]).max() <= 1.0
+
+
 @pytest.mark.parametrize("name", ["err_singular", "err_vloop"])
 def test_program_singular(name):
     flat, steps, dt, src = _inputs(name)
