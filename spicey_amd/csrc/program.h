@@ -136,6 +136,7 @@ struct SpiceyResident {
 struct SpiceyRun {
   int32_t n_inst;
   int32_t want_currents;
+  int32_t debug_empty_phases;  // diagnostics: extra empty barrier phases per solve (0 in production)
   int64_t steps;
   double dt;
   // parameters

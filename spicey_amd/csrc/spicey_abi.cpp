@@ -269,6 +269,7 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   SpiceyRun R{};
   R.n_inst = h->n_inst;
   R.want_currents = d_out_i != nullptr;
+  R.debug_empty_phases = h->opt.reserved[0] >= 100 ? h->opt.reserved[0] - 100 : 0;
   R.steps = steps;
   R.dt = dt;
   R.R_val = h->d_R; R.C_val = h->d_C; R.L_val = h->d_L;

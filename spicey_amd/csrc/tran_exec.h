@@ -257,7 +257,25 @@ struct TranPhases {
       const uint32_t ti = SPICEY_IDX(tgt);
       double acc[K];
       for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)ti * K + k];
-      for (uint32_t j = 0; j < cnt; j++) {
+      uint32_t j = 0;
+      // long product lists (dense fronts of large circuits): 4 products' indices and operands are in flight at once —
+      // one dependent L2 round trip per 4 products instead of per product; the summation order is unchanged
+      for (; j + 4 <= cnt; j += 4) {
+        uint32_t li[4], di[4], ui[4];
+        for (int q = 0; q < 4; q++) {
+          li[q] = P.upd_pairs[off + ((j + q) * 3 + 0) * 64];
+          di[q] = P.upd_pairs[off + ((j + q) * 3 + 1) * 64];
+          ui[q] = P.upd_pairs[off + ((j + q) * 3 + 2) * 64];
+        }
+        double lv[4][K], dv[4][K], uv[4][K];
+        for (int q = 0; q < 4; q++)
+          for (int k = 0; k < K; k++) {
+            lv[q][k] = c.W[(size_t)li[q] * K + k]; dv[q][k] = c.W[(size_t)di[q] * K + k]; uv[q][k] = c.W[(size_t)ui[q] * K + k];
+          }
+        for (int q = 0; q < 4; q++)
+          for (int k = 0; k < K; k++) acc[k] = fma(-(lv[q][k] * dv[q][k]), uv[q][k], acc[k]);
+      }
+      for (; j < cnt; j++) {
         const uint32_t li = P.upd_pairs[off + (j * 3 + 0) * 64];
         const uint32_t di = P.upd_pairs[off + (j * 3 + 1) * 64];
         const uint32_t ui = P.upd_pairs[off + (j * 3 + 2) * 64];
@@ -285,7 +303,17 @@ struct TranPhases {
       const uint32_t off = P.bk_slice[s].off + lane;
       double acc[K];
       for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)xi * K + k];
-      for (uint32_t j = 0; j < cnt; j++) {
+      uint32_t j = 0;
+      for (; j + 4 <= cnt; j += 4) {
+        uint32_t ui[4], xb[4];
+        for (int q = 0; q < 4; q++) { ui[q] = P.bk_pairs[off + ((j + q) * 2 + 0) * 64]; xb[q] = P.bk_pairs[off + ((j + q) * 2 + 1) * 64]; }
+        double uv[4][K], xv[4][K];
+        for (int q = 0; q < 4; q++)
+          for (int k = 0; k < K; k++) { uv[q][k] = c.W[(size_t)ui[q] * K + k]; xv[q][k] = c.W[(size_t)xb[q] * K + k]; }
+        for (int q = 0; q < 4; q++)
+          for (int k = 0; k < K; k++) acc[k] = fma(-uv[q][k], xv[q][k], acc[k]);
+      }
+      for (; j < cnt; j++) {
         const uint32_t ui = P.bk_pairs[off + (j * 2 + 0) * 64];
         const uint32_t xb = P.bk_pairs[off + (j * 2 + 1) * 64];
         for (int k = 0; k < K; k++) acc[k] = fma(-c.W[(size_t)ui * K + k], c.W[(size_t)xb * K + k], acc[k]);
@@ -914,6 +942,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
     int iter = 0;
     for (;;) {
       ex.phase(SPICEY_PH_B, [&](int tid) { p2.b_stamp(tid, ex.template regs<Regs>(tid)); });
+      for (int d = 0; d < R.debug_empty_phases; d++) ex.phase(SPICEY_PH_S, [&](int) {});  // diagnostics: cost of a bare phase
       // factor levels [0, u_end) | tail [u_end, k_begin) by one wave | backward levels [k_begin, 2 nL)
       for (int p = 0; p < u_end; p++) {
         if (p < 64 ? !((active >> p) & 1) : P.ph_cnt[p] == 0) continue;

@@ -71,14 +71,14 @@ class Handle:
     """Owns one SpiceyHandle (one topology, n_inst instances, one device)."""
 
     def __init__(self, flat: abi.FlatCircuit, device: int = 0, threads: int = 0, inst_per_wg: int = 0,
-                 force_global: bool = False, profile: bool = False, interpreter: int = 0, no_tail: bool = False):
+                 force_global: bool = False, profile: bool = False, interpreter: int = 0, no_tail: bool = False, debug_empty_phases: int = 0):
         self.L = load()
         self.flat = flat
         opt = abi.SpiceyOptions()
         opt.device, opt.threads, opt.inst_per_wg, opt.want_currents, opt.force_global = device, threads, inst_per_wg, 1, int(force_global)
         opt.profile = int(profile)
         opt.interpreter = int(interpreter)
-        opt.reserved[0] = 1 if no_tail else 0
+        opt.reserved[0] = 1 if no_tail else (100 + debug_empty_phases if debug_empty_phases else 0)
         d = flat.desc()
         hp = C.c_void_p()
         rc = self.L.spicey_create(C.byref(d), C.byref(opt), C.byref(hp))
