@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="instances per GPU")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--inst-per-wg", type=int, default=0)
+    ap.add_argument("--geometry", type=int, default=0, help="0 auto, 1 latency (one workgroup per CU), 2 throughput (two per CU)")
     ap.add_argument("--no-currents", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-instance", action="store_true", help="also time ONE instance (config 2/3 as written)")
@@ -129,7 +130,7 @@ def main():
     flat, _, _, _ = synth.chain_batch(args.workload, n, [i + 1 for i in mine], tran=tran)
 
     def alloc_and_make(batch_flat):
-        h = Handle(batch_flat, device=local_rank, threads=args.threads, inst_per_wg=args.inst_per_wg)
+        h = Handle(batch_flat, device=local_rank, threads=args.threads, inst_per_wg=args.inst_per_wg, geometry=args.geometry)
         info = h.info()
         ov = torch.empty((batch_flat.n_inst, tsteps + 1, info["n_out"]), dtype=torch.float64, device=dev)
         oi = None if args.no_currents else torch.empty((batch_flat.n_inst, tsteps + 1, info["n_cur"]), dtype=torch.float64, device=dev)
@@ -188,7 +189,7 @@ def main():
                 "instances_total": B * n_gpus, "parallelism": f"instance-sharded x{n_gpus}, no data-path collective",
                 "inst_per_workgroup": info["inst_per_wg"], "threads": info["threads"], "lds_bytes": info["lds_bytes"],
                 "nnz_a": info["nnz_a"], "nnz_lu": info["nnz_lu"], "levels": info["n_levels"],
-                "interpreter": info["interpreter"], "resident_tasks": info["resident_tasks"], "streamed_tasks": info["streamed_tasks"],
+                "interpreter": info["interpreter"], "geometry": info["geometry"], "tail_levels": info["tail_levels"], "resident_tasks": info["resident_tasks"], "streamed_tasks": info["streamed_tasks"],
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

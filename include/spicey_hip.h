@@ -86,7 +86,9 @@ typedef struct SpiceyOptions {
   int32_t force_global;  /* 1: keep the LU workspace in HBM/L2 even if it fits LDS (testing) */
   int32_t profile;       /* 1: accumulate per-phase shader-clock cycles (spicey_debug_phase_cycles) */
   int32_t interpreter;   /* 0 auto; 1 = v1 (32-bit sliced task lists from L2); 2 = v2 (register-resident 16-bit records) */
-  int32_t reserved[1];
+  int32_t geometry;      /* v2 only. 0 auto; 1 = latency: one workgroup per CU, whole program in registers;
+                            2 = throughput: two 512-thread workgroups per CU (<= 128 VGPRs, wide levels streamed) */
+  int32_t debug;         /* diagnostics: bit 0 = no tail merge; bits 8.. = extra empty phases per solve */
 } SpiceyOptions;
 
 typedef struct SpiceyInfo {
@@ -101,6 +103,8 @@ typedef struct SpiceyInfo {
   int32_t n_out;       /* recorded node-voltage columns */
   int32_t n_workgroups;
   int32_t interpreter;      /* 1 or 2, see SpiceyOptions */
+  int32_t geometry;         /* 1 or 2 (v2), see SpiceyOptions */
+  int32_t tail_levels;      /* v2: elimination-tree levels merged into the single-wave tail phase */
   int32_t resident_slots;   /* v2: 16-byte task records per thread kept in VGPRs */
   int64_t resident_tasks;   /* v2: factor/backward tasks held in registers */
   int64_t streamed_tasks;   /* v2: tasks still fetched from L2 every step */

@@ -178,7 +178,7 @@ size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds, int tail_n) {
   if (!lds) return 64;
   size_t b = ((size_t)P.nW + P.nU + P.nGdyn) * K * sizeof(double) + ((size_t)P.nS * K + 4) * sizeof(int32_t);
   b = ((b + 15) & ~size_t(15)) + SPICEY_PH_SLOTS * sizeof(unsigned long long);  // + profiling accumulators
-  b = ((b + 15) & ~size_t(15)) + (size_t)tail_n * 64 * 32;                          // + pre-decoded tail task records
+  b = ((b + 15) & ~size_t(15)) + (size_t)tail_n * 64 * 16;                          // + tail task records
   return (b + 15) & ~size_t(15);
 }
 
@@ -211,14 +211,20 @@ hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bo
 //   T <= 256 : 32 slots, 12 entries, 4 elements per thread (one wave per SIMD: up to 512 VGPRs; K = 1 or 2)
 //   T <= 512 : 16 slots,  8 entries, 2 elements per thread (<= 256 VGPRs; K = 1 only)
 //   T <= 1024:  8 slots,  4 entries, 1 element  per thread (<= 128 VGPRs; K = 1 only)
-int spicey_v2_rmax(int threads) { return threads <= 256 ? 32 : (threads <= 512 ? 16 : 8); }
-int spicey_v2_nsv(int threads) { return threads <= 256 ? 12 : (threads <= 512 ? 8 : 4); }
-int spicey_v2_nel(int threads) { return threads <= 256 ? 4 : (threads <= 512 ? 2 : 1); }
+// `packed` = the two-workgroups-per-CU geometry: 512 threads, <= 128 VGPRs; only 4 slots stay resident (the small,
+// latency-critical phases), the wide bottom levels are streamed from L2 with the records prefetched in batches.
+int spicey_v2_rmax(int threads, bool packed) { return packed ? 4 : (threads <= 256 ? 32 : (threads <= 512 ? 16 : 8)); }
+int spicey_v2_nsv(int threads, bool packed) { return packed ? 6 : (threads <= 256 ? 12 : (threads <= 512 ? 8 : 4)); }
+int spicey_v2_nel(int threads, bool packed) { return packed ? 2 : (threads <= 256 ? 4 : (threads <= 512 ? 2 : 1)); }
 int spicey_v2_max_threads(int K) { return K == 1 ? 1024 : 256; }
 
 hipError_t spicey_launch_tran_v2(const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, int K, int grid, int threads,
-                                 hipStream_t st) {
+                                 hipStream_t st, bool packed) {
   const size_t bytes = spicey_lds_bytes(P, K, true, Q.tail_n);
+  if (packed) {
+    if (K == 1 && threads == 512) return launch_v2_t<1, 4, 6, 2, 512, 4>(P, Q, R, grid, threads, bytes, st);
+    return hipErrorInvalidValue;
+  }
   if (threads <= 256) {
     switch (K) {
       case 1: return launch_v2_t<1, 32, 12, 4, 256, 1>(P, Q, R, grid, threads, bytes, st);

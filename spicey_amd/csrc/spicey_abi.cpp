@@ -20,6 +20,7 @@ struct SpiceyHandle {
   SpiceyProg dprog{};
   SpiceyResident dres{};
   int interp = 1;
+  bool packed = false;  // two 512-thread workgroups per CU
   void *d_res = nullptr;
   SpiceyOptions opt{};
   int n_inst = 0, n_nodes = 0;
@@ -155,7 +156,6 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   if (K != 0 && K != 1 && K != 2 && K != 4) { h->err = "inst_per_wg must be 0, 1, 2 or 4"; return fail(SPICEY_ERR_BAD_DESC); }
   if (P.nS > 0) K = 1;  // the switch iteration count is per instance: no interleaving
   if (K == 0) K = 1;  // measured: one instance per workgroup beats two interleaved ones (VGPR pressure in phase Z)
-  (void)ncu;
   if (K > h->n_inst) K = 1;
   h->lds = want_lds && spicey_lds_bytes(P, K, true) <= SPICEY_LDS_MAX;
   if (!h->lds && want_lds && K > 1) {
@@ -173,11 +173,22 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   h->grid = (h->n_inst + K - 1) / K;
   h->lds_bytes = spicey_lds_bytes(P, K, h->lds);
   if (h->interp == 2) {
-    // tail levels go to LDS: as many as fit beside the workspace (2 KB each), at most 24
+    // geometry: "throughput" packs two 512-thread workgroups on a CU (needs K = 1, half the LDS, and the per-thread
+    // resident items of a 512-thread workgroup); chosen automatically once the batch can fill every CU twice
     const size_t base = spicey_lds_bytes(P, K, true, 0);
-    int max_tail = (int)std::min<size_t>(24, base < SPICEY_LDS_MAX ? (SPICEY_LDS_MAX - base) / 2048 : 0);
-    if (h->opt.reserved[0] == 1) max_tail = 0;  // diagnostics: disable the tail merge
-    spicey_build_resident(h->hp, h->T, spicey_v2_rmax(h->T), h->hres, max_tail);
+    const int widest = std::max(std::max(P.n, P.nOut), std::max(std::max(P.nR, P.nC), P.nD));
+    const bool packable = K == 1 && base <= SPICEY_LDS_MAX / 2 && widest <= spicey_v2_nel(512, true) * 512 &&
+                          P.nRestore <= spicey_v2_nsv(512, true) * 512 && (h->opt.threads == 0 || h->opt.threads == 512);
+    if (h->opt.geometry == 2 && !packable) { h->err = "geometry 2 needs inst_per_wg = 1, <= 80 KB of LDS per instance and <= 1024 unknowns"; return fail(SPICEY_ERR_BAD_DESC); }
+    if (h->opt.geometry < 0 || h->opt.geometry > 2) { h->err = "geometry must be 0, 1 or 2"; return fail(SPICEY_ERR_BAD_DESC); }
+    h->packed = packable && (h->opt.geometry == 2 || (h->opt.geometry == 0 && h->n_inst >= 2 * ncu && h->opt.threads == 0));
+    if (h->packed) { h->T = 512; h->grid = (h->n_inst + K - 1) / K; }
+    // tail levels go to LDS: as many as fit beside the workspace (1 KB each), at most 24; the packed geometry
+    // must leave room for a second workgroup on the CU
+    const size_t lds_cap = h->packed ? SPICEY_LDS_MAX / 2 : SPICEY_LDS_MAX;
+    int max_tail = (int)std::min<size_t>(24, base < lds_cap ? (lds_cap - base) / 1024 : 0);
+    if (h->opt.debug & 1) max_tail = 0;  // diagnostics: disable the tail merge
+    spicey_build_resident(h->hp, h->T, spicey_v2_rmax(h->T, h->packed), h->hres, max_tail);
     h->lds_bytes = spicey_lds_bytes(P, K, true, h->hres.tail_n);
   }
 
@@ -248,6 +259,8 @@ extern "C" int32_t spicey_get_info(SpiceyHandle *h, SpiceyInfo *info) {
   info->n_out = h->hp.hdr.nOut;
   info->n_workgroups = h->grid;
   info->interpreter = h->interp;
+  info->geometry = h->interp == 2 ? (h->packed ? 2 : 1) : 0;
+  info->tail_levels = h->hres.tail_n;
   info->resident_slots = h->interp == 2 ? h->hres.rmax : 0;
   info->resident_tasks = h->hres.resident_tasks;
   info->streamed_tasks = h->hres.streamed_tasks;
@@ -269,7 +282,7 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   SpiceyRun R{};
   R.n_inst = h->n_inst;
   R.want_currents = d_out_i != nullptr;
-  R.debug_empty_phases = h->opt.reserved[0] >= 100 ? h->opt.reserved[0] - 100 : 0;
+  R.debug_empty_phases = h->opt.debug >> 8;
   R.steps = steps;
   R.dt = dt;
   R.R_val = h->d_R; R.C_val = h->d_C; R.L_val = h->d_L;
@@ -281,7 +294,7 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   R.status = h->d_status; R.solves = h->d_solves; R.prof = h->d_prof;
   if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, (size_t)h->grid * 72 * sizeof(unsigned long long), st));
   HIPCHK(h, hipEventRecord(h->ev0, st));
-  if (h->interp == 2) HIPCHK(h, spicey_launch_tran_v2(h->dprog, h->dres, R, h->K, h->grid, h->T, st));
+  if (h->interp == 2) HIPCHK(h, spicey_launch_tran_v2(h->dprog, h->dres, R, h->K, h->grid, h->T, st, h->packed));
   else HIPCHK(h, spicey_launch_tran(h->dprog, R, h->K, h->lds, h->grid, h->T, st));
   HIPCHK(h, hipEventRecord(h->ev1, st));
   h->pending = true;

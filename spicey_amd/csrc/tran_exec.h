@@ -520,55 +520,6 @@ SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_
   }
 }
 
-// Tail task from a pre-decoded LDS record (see the loader in spicey_tran_run_v2).
-template <int K, bool KTASK>
-SPICEY_HD void spicey_exec_tail(const WgCtx<K> &c, const uint16_t *ovf, const uint32_t *r) {
-  const uint32_t meta = r[0];
-  if (!(meta & (SPICEY_R16_VALID << 8))) return;
-  const uint32_t cnt = meta & 0xffu, tgt = r[1];
-  double acc[K];
-  if (cnt <= 2) {
-    double o[6][K];
-    for (int k = 0; k < K; k++) acc[k] = c.W[tgt + k];
-    for (int j = 0; j < 6; j++)
-      for (int k = 0; k < K; k++) o[j][k] = c.W[r[2 + j] + k];
-    for (int k = 0; k < K; k++) {
-      if (KTASK) {  // operands: d, u0, x0, u1, x1
-        const double s0 = fma(-o[1][k], o[2][k], acc[k]);
-        acc[k] = cnt >= 1 ? s0 : acc[k];
-        const double s1 = fma(-o[3][k], o[4][k], acc[k]);
-        acc[k] = (cnt == 2 ? s1 : acc[k]) * o[0][k];
-      } else {  // operands: l0, d0, u0, l1, d1, u1
-        const double s0 = fma(-(o[0][k] * o[1][k]), o[2][k], acc[k]);
-        acc[k] = cnt >= 1 ? s0 : acc[k];
-        const double s1 = fma(-(o[3][k] * o[4][k]), o[5][k], acc[k]);
-        acc[k] = cnt == 2 ? s1 : acc[k];
-      }
-    }
-  } else {
-    for (int k = 0; k < K; k++) acc[k] = c.W[tgt + k];
-    const uint16_t *o = ovf + r[7];
-    for (uint32_t j = 0; j < cnt; j++) {
-      if (KTASK) {
-        const uint32_t u = o[2 * j], x = o[2 * j + 1];
-        for (int k = 0; k < K; k++) acc[k] = fma(-c.W[(size_t)u * K + k], c.W[(size_t)x * K + k], acc[k]);
-      } else {
-        const uint32_t l = o[3 * j], d = o[3 * j + 1], u = o[3 * j + 2];
-        for (int k = 0; k < K; k++) acc[k] = fma(-(c.W[(size_t)l * K + k] * c.W[(size_t)d * K + k]), c.W[(size_t)u * K + k], acc[k]);
-      }
-    }
-    if (KTASK)
-      for (int k = 0; k < K; k++) acc[k] *= c.W[r[2] + k];
-  }
-  if (!KTASK && (meta & (SPICEY_R16_RECIP << 8))) {
-    for (int k = 0; k < K; k++) {
-      if (fabs(acc[k]) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
-      acc[k] = spicey_rcp(acc[k]);
-    }
-  }
-  for (int k = 0; k < K; k++) c.W[tgt + k] = acc[k];
-}
-
 template <int K, int RMAX, int NSV, int NEL, bool KTASK>
 SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, const WgCtx<K> &c, ResRegs<K, RMAX, NSV, NEL> &rr, int tid,
                                int T, int p, bool streamed) {
@@ -604,10 +555,24 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
   if (!streamed) return;
   const uint32_t sc = Q.st_cnt[p];
   if (sc) {
+    // streamed phase (did not fit the resident slots): double-buffered — the next record's L2 fetch is in flight
+    // while the current task executes.  (Fetching 4 records up front was measured slower: +16 live VGPRs pushed
+    // the 1024-thread kernel to its 128-register cap.)
     const uint32_t *base = P.rec16 + (size_t)Q.st_first[p] * 4;
-    for (uint32_t j = (uint32_t)tid; j < sc; j += (uint32_t)T) {
+    uint32_t j = (uint32_t)tid;
+    if (j < sc) {
       const uint32_t *r = base + (size_t)j * 4;
-      spicey_exec_rec16<K, KTASK>(c, P.ovf16, r[0], r[1], r[2], r[3]);
+      uint32_t c0 = r[0], c1 = r[1], c2 = r[2], c3 = r[3];
+      for (;;) {
+        const uint32_t jn = j + (uint32_t)T;
+        const bool more = jn < sc;
+        const uint32_t *rn = base + (size_t)(more ? jn : j) * 4;
+        const uint32_t n0 = rn[0], n1 = rn[1], n2 = rn[2], n3 = rn[3];
+        spicey_exec_rec16<K, KTASK>(c, P.ovf16, c0, c1, c2, c3);
+        if (!more) break;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        j = jn;
+      }
     }
   }
 }
@@ -907,19 +872,11 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
     if (tid == 0) { c.flags[0] = 0; c.flags[1] = 0; c.flags[2] = -1; }
     ph.p0_gstat(tid);
     p2.load_resident(tid, Q, ex.template regs<Regs>(tid));
-    for (int i = tid; i < Q.tail_n * 64; i += T) {
-      // tail records -> LDS, pre-decoded: word 0 = meta (0 = no task), word 1 = target, words 2..7 = operands, all
-      // as element offsets into W (x K): the single wave that runs the tail spends no instructions on unpacking
+    for (int i = tid; i < Q.tail_n * 64; i += T) {  // tail records -> LDS (16 bytes each; no task = all zero)
       const int p = Q.tail_first + (i >> 6), lane = i & 63;
       const bool have = (uint32_t)lane < P.ph_cnt[p];
       const uint32_t *src = P.rec16 + ((size_t)P.ph_first[p] + (have ? lane : 0)) * 4;
-      const uint32_t w0 = have ? src[0] : 0u, w1 = src[1], w2 = src[2], w3 = src[3];
-      uint32_t *dst = c.tail + (size_t)i * 8;
-      dst[0] = w0 >> 16;
-      dst[1] = (w0 & 0xffffu) * K;
-      dst[2] = (w1 & 0xffffu) * K; dst[3] = (w1 >> 16) * K; dst[4] = (w2 & 0xffffu) * K;
-      dst[5] = (w2 >> 16) * K; dst[6] = (w3 & 0xffffu) * K; dst[7] = (w3 >> 16) * K;
-      if ((w0 >> 16 & 0xffu) > 2) dst[7] = w3;  // overflow offset stays raw
+      for (int w = 0; w < 4; w++) c.tail[(size_t)i * 4 + w] = have ? src[w] : 0u;
     }
   });
   ex.phase(SPICEY_PH_PRO, [&](int tid) { ph.p1_static(tid); });
@@ -952,9 +909,9 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
       }
       if (k_begin > u_end) {
         ex.tail_phase(SPICEY_PH_U0 + 31, k_begin - u_end, [&](int tid, int lvl) {
-          const uint32_t *r = c.tail + ((size_t)lvl * 64 + tid) * 8;
-          if (u_end + lvl < nL) spicey_exec_tail<K, false>(c, P.ovf16, r);
-          else spicey_exec_tail<K, true>(c, P.ovf16, r);
+          const uint32_t *r = c.tail + ((size_t)lvl * 64 + tid) * 4;
+          if (u_end + lvl < nL) spicey_exec_rec16<K, false>(c, P.ovf16, r[0], r[1], r[2], r[3]);
+          else spicey_exec_rec16<K, true>(c, P.ovf16, r[0], r[1], r[2], r[3]);
         });
       }
       for (int p = k_begin; p < 2 * nL; p++) {

@@ -71,14 +71,15 @@ class Handle:
     """Owns one SpiceyHandle (one topology, n_inst instances, one device)."""
 
     def __init__(self, flat: abi.FlatCircuit, device: int = 0, threads: int = 0, inst_per_wg: int = 0,
-                 force_global: bool = False, profile: bool = False, interpreter: int = 0, no_tail: bool = False, debug_empty_phases: int = 0):
+                 force_global: bool = False, profile: bool = False, interpreter: int = 0, geometry: int = 0, no_tail: bool = False, debug_empty_phases: int = 0):
         self.L = load()
         self.flat = flat
         opt = abi.SpiceyOptions()
         opt.device, opt.threads, opt.inst_per_wg, opt.want_currents, opt.force_global = device, threads, inst_per_wg, 1, int(force_global)
         opt.profile = int(profile)
         opt.interpreter = int(interpreter)
-        opt.reserved[0] = 1 if no_tail else (100 + debug_empty_phases if debug_empty_phases else 0)
+        opt.geometry = int(geometry)
+        opt.debug = (1 if no_tail else 0) | (int(debug_empty_phases) << 8)
         d = flat.desc()
         hp = C.c_void_p()
         rc = self.L.spicey_create(C.byref(d), C.byref(opt), C.byref(hp))
@@ -161,8 +162,10 @@ class Handle:
 class HipBackend:
     """Backend interface used by spicey_amd.simulate: one handle per call (the reference API is stateless)."""
 
-    def __init__(self, device: int = 0, threads: int = 0, inst_per_wg: int = 0, force_global: bool = False, interpreter: int = 0):
-        self.kw = dict(device=device, threads=threads, inst_per_wg=inst_per_wg, force_global=force_global, interpreter=interpreter)
+    def __init__(self, device: int = 0, threads: int = 0, inst_per_wg: int = 0, force_global: bool = False, interpreter: int = 0,
+                 geometry: int = 0):
+        self.kw = dict(device=device, threads=threads, inst_per_wg=inst_per_wg, force_global=force_global, interpreter=interpreter,
+                       geometry=geometry)
         self.info: Optional[dict] = None
 
     def run(self, flat: abi.FlatCircuit, steps: int, dt: float, src: np.ndarray, want_currents: bool = True,

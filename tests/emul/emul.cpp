@@ -63,7 +63,7 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
       HostResident hr;
       spicey_build_resident(hp, T, rmax, hr, 24);
       SpiceyResident Q = hr.bind(hr.blob.data());
-      std::vector<uint32_t> tail((size_t)(hr.tail_n + 1) * 64 * 8);
+      std::vector<uint32_t> tail((size_t)(hr.tail_n + 1) * 64 * 4);
       c.tail = tail.data();
       // NSV = 2 resident entries per thread: small on purpose so that tests also cover the streamed remainder
       // NEL = 2 resident elements / rows per thread: with the small T the tests use, the remainder loops run too.

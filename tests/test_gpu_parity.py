@@ -232,6 +232,19 @@ def test_degenerate_shapes(oracle_backend):
     assert got["status"] == 0 and tol_ratio(got["out_v"], ref["out_v"]).max() <= 1.0
 
 
+def test_throughput_geometry_two_workgroups_per_cu(oracle_backend):
+    """geometry 2: two 512-thread workgroups per CU, <= 128 VGPRs, wide levels streamed with double buffering."""
+    from spicey_amd.lib import HipBackend
+    flat, dt, steps, src = synth.chain_batch("diode_chain", 700, range(1, 6), tran=".tran 1e-6 2e-5")
+    be = HipBackend(geometry=2)
+    got = be.run(flat, steps, dt, src)
+    assert got["status"] == 0 and be.info["geometry"] == 2 and be.info["threads"] == 512 and be.info["lds_bytes"] <= 80 * 1024
+    ref = oracle_backend.run(flat, steps, dt, src)
+    assert tol_ratio(got["out_v"], ref["out_v"]).max() <= 1.0 and tol_ratio(got["out_i"], ref["out_i"]).max() <= 1.0
+    lat = HipBackend(geometry=1).run(flat, steps, dt, src)
+    assert np.array_equal(lat["out_v"], got["out_v"]) and np.array_equal(lat["out_i"], got["out_i"])  # same bits in both geometries
+
+
 def test_determinism_across_handles_and_geometries():
     """Regression: results must not depend on what ran before (stale scratch / registers) nor on the workgroup
     geometry.  The gather-form program has a fixed summation order, so outputs are bit-identical across thread
@@ -240,14 +253,14 @@ def test_determinism_across_handles_and_geometries():
     flat, dt, steps, src = synth.chain_batch("rc_ladder", 1000, [1], tran=".tran 1e-6 1e-3")
     f2, dt2, st2, src2 = synth.chain_batch("diode_chain", 40, range(1, 8), tran=".tran 1e-6 3e-5")
     first = None
-    for T, interp in [(0, 0), (256, 2), (512, 2), (1024, 2), (256, 2), (512, 1), (256, 1), (0, 0)]:
+    for T, interp, geom in [(0, 0, 0), (256, 2, 0), (512, 2, 0), (1024, 2, 0), (0, 2, 2), (256, 2, 0), (512, 1, 0), (256, 1, 0), (0, 0, 2), (0, 0, 0)]:
         HipBackend(threads=64).run(f2, st2, dt2, src2)  # something different in between
-        r = HipBackend(threads=T, interpreter=interp).run(flat, steps, dt, src)
+        r = HipBackend(threads=T, interpreter=interp, geometry=geom).run(flat, steps, dt, src)
         assert r["status"] == 0
         if first is None:
             first = r
-        assert np.array_equal(r["out_v"], first["out_v"]), (T, interp)
-        assert np.array_equal(r["out_i"], first["out_i"]), (T, interp)
+        assert np.array_equal(r["out_v"], first["out_v"]), (T, interp, geom)
+        assert np.array_equal(r["out_i"], first["out_i"]), (T, interp, geom)
     assert not np.any(first["out_i"][0, 0]) and not np.any(first["out_v"][0, 0])  # step 0 of a ladder at rest: all zero
 
 

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--interp", type=int, default=0)
     ap.add_argument("--no-tail", type=int, default=0)
     ap.add_argument("--empty", type=int, default=0)
+    ap.add_argument("--packed", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for cfg in args.configs.split(","):
@@ -37,7 +38,7 @@ def main():
         ckt = parseNetlist(getattr(synth, args.workload)(args.n, seed=1, tran=".tran 1e-6 1e-2"))
         steps = args.steps
         src = torch.tensor(abi.source_table(ckt, 1e-6, steps), device=dev)
-        h = Handle(flat, threads=T, inst_per_wg=K, force_global=bool(args.force_global), profile=bool(args.profile), interpreter=args.interp, no_tail=bool(args.no_tail), debug_empty_phases=args.empty)
+        h = Handle(flat, threads=T, inst_per_wg=K, force_global=bool(args.force_global), profile=bool(args.profile), interpreter=args.interp, no_tail=bool(args.no_tail), debug_empty_phases=args.empty, geometry=2 if args.packed else 0)
         info = h.info()
         out_v = torch.empty((B, steps + 1, info["n_out"]), dtype=torch.float64, device=dev)
         out_i = torch.empty((B, steps + 1, info["n_cur"]), dtype=torch.float64, device=dev) if args.currents else None
@@ -52,7 +53,7 @@ def main():
             ms = h.kernel_ms()
             best = ms if best is None else min(best, ms)
         solves = h.solves()
-        rec = dict(interp=info['interpreter'], rslots=info['resident_slots'], rtasks=info['resident_tasks'], stasks=info['streamed_tasks'], workload=args.workload, n=args.n, B=B, K=info["inst_per_wg"], T=info["threads"], lds=info["lds_bytes"],
+        rec = dict(interp=info['interpreter'], geom=info['geometry'], tail=info['tail_levels'], rslots=info['resident_slots'], rtasks=info['resident_tasks'], stasks=info['streamed_tasks'], workload=args.workload, n=args.n, B=B, K=info["inst_per_wg"], T=info["threads"], lds=info["lds_bytes"],
                    steps=steps, kernel_ms=best, solves=solves, solves_per_s=solves / (best * 1e-3), wall_ms=(t1 - t0) * 1e3,
                    us_per_step=best * 1e3 / (steps + 1), levels=info["n_levels"], nnz_lu=info["nnz_lu"], currents=args.currents,
                    finite=bool(torch.isfinite(out_v[:, -1]).all().item()))
