@@ -36,6 +36,8 @@
 // Same for wave-uniform values (instance index): per-instance base pointers derived from it are then formed
 // inside the phase that needs them instead of living in (spilled) SGPRs across the whole time loop.
 #define SPICEY_OPAQUE_S(x) asm volatile("" : "+s"(x))
+// wave vote: true if the condition holds in any active lane (a scalar branch: whole waves skip work nobody needs)
+#define SPICEY_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
 #define SPICEY_NOUNROLL _Pragma("unroll 1")  // thread-strided loops run 1-2 trips: unrolling only costs VGPRs
 #define SPICEY_SCHED_FENCE __builtin_amdgcn_sched_barrier(0)  // keep the K instances' code from being interleaved
 #else
@@ -44,6 +46,7 @@
 #define SPICEY_UNIFORM(x) (x)
 #define SPICEY_OPAQUE(x) (void)(x)
 #define SPICEY_OPAQUE_S(x) (void)(x)
+#define SPICEY_WAVE_ANY(c) true
 #endif
 
 // phase tags (profiling slots, SpiceyRun::prof)
@@ -464,18 +467,23 @@ SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_
     const uint32_t d = w1 & 0xffffu;
     if (cnt <= 2) {
       const uint32_t u0 = w1 >> 16, x0 = w2 & 0xffffu, u1 = w2 >> 16, x1 = w3 & 0xffffu;
+      const bool two = SPICEY_WAVE_ANY(cnt == 2);  // tasks are sorted by count: most waves are uniform
       double a0[K], b0[K], a1[K], b1[K], dv[K];
       for (int k = 0; k < K; k++) {
         acc[k] = c.W[(size_t)tgt * K + k];
         a0[k] = c.W[(size_t)u0 * K + k]; b0[k] = c.W[(size_t)x0 * K + k];
-        a1[k] = c.W[(size_t)u1 * K + k]; b1[k] = c.W[(size_t)x1 * K + k];
         dv[k] = c.W[(size_t)d * K + k];
       }
+      if (two)
+        for (int k = 0; k < K; k++) { a1[k] = c.W[(size_t)u1 * K + k]; b1[k] = c.W[(size_t)x1 * K + k]; }
       for (int k = 0; k < K; k++) {  // explicit fma: the same rounding in every interpreter and geometry
         const double s0 = fma(-a0[k], b0[k], acc[k]);
         acc[k] = cnt >= 1 ? s0 : acc[k];
-        const double s1 = fma(-a1[k], b1[k], acc[k]);
-        acc[k] = (cnt == 2 ? s1 : acc[k]) * dv[k];
+        if (two) {
+          const double s1 = fma(-a1[k], b1[k], acc[k]);
+          acc[k] = cnt == 2 ? s1 : acc[k];
+        }
+        acc[k] *= dv[k];
       }
     } else {
       for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)tgt * K + k];
@@ -490,17 +498,21 @@ SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_
   } else {
     if (cnt <= 2) {
       const uint32_t l0 = w1 & 0xffffu, d0 = w1 >> 16, u0 = w2 & 0xffffu, l1 = w2 >> 16, d1 = w3 & 0xffffu, u1 = w3 >> 16;
+      const bool two = SPICEY_WAVE_ANY(cnt == 2);
       double p0[K], q0[K], r0[K], p1[K], q1[K], r1[K];
       for (int k = 0; k < K; k++) {
         acc[k] = c.W[(size_t)tgt * K + k];
         p0[k] = c.W[(size_t)l0 * K + k]; q0[k] = c.W[(size_t)d0 * K + k]; r0[k] = c.W[(size_t)u0 * K + k];
-        p1[k] = c.W[(size_t)l1 * K + k]; q1[k] = c.W[(size_t)d1 * K + k]; r1[k] = c.W[(size_t)u1 * K + k];
       }
+      if (two)
+        for (int k = 0; k < K; k++) { p1[k] = c.W[(size_t)l1 * K + k]; q1[k] = c.W[(size_t)d1 * K + k]; r1[k] = c.W[(size_t)u1 * K + k]; }
       for (int k = 0; k < K; k++) {
         const double s0 = fma(-(p0[k] * q0[k]), r0[k], acc[k]);
         acc[k] = cnt >= 1 ? s0 : acc[k];
-        const double s1 = fma(-(p1[k] * q1[k]), r1[k], acc[k]);
-        acc[k] = cnt == 2 ? s1 : acc[k];
+        if (two) {
+          const double s1 = fma(-(p1[k] * q1[k]), r1[k], acc[k]);
+          acc[k] = cnt == 2 ? s1 : acc[k];
+        }
       }
     } else {
       for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)tgt * K + k];
@@ -700,7 +712,11 @@ struct TranPhases2 {
       const uint32_t e = (uint32_t)(tid + j * T);
       uint32_t dd = rr.dd[j];
       SPICEY_OPAQUE(dd);
-      if (!(dd >> 31)) stamp_entry(e, dd, rr.sv[j]);
+      if (SPICEY_WAVE_ANY((dd & 0x7fffffffu) != 0u)) {  // dynamic entries are numbered first: only the first slot(s) take this path
+        if (!(dd >> 31)) stamp_entry(e, dd, rr.sv[j]);
+      } else if (!(dd >> 31)) {
+        for (int k = 0; k < K; k++) c.W[(size_t)e * K + k] = rr.sv[j][k];
+      }
     }
     SPICEY_NOUNROLL
     for (int e = tid + NSV * T; e < P.nRestore; e += T) {  // entries beyond the resident capacity
