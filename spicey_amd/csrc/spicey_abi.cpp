@@ -155,12 +155,18 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   const bool want_lds = !h->opt.force_global;
   if (K != 0 && K != 1 && K != 2 && K != 4) { h->err = "inst_per_wg must be 0, 1, 2 or 4"; return fail(SPICEY_ERR_BAD_DESC); }
   if (P.nS > 0) K = 1;  // the switch iteration count is per instance: no interleaving
-  if (K == 0) K = 1;  // measured: one instance per workgroup beats two interleaved ones (VGPR pressure in phase Z)
+  if (K == 0) {
+    // LDS path: one instance per workgroup (measured faster than two interleaved ones: VGPR pressure in phase Z).
+    // Global-workspace path (large circuits): once the batch exceeds the CUs, interleaving 2-4 instances shares
+    // the index stream and fills more of every gathered cache line (rcd_mesh(50) x 1024: ~3x with K = 4).
+    K = 1;
+    if (!want_lds || spicey_lds_bytes(P, 1, true) > SPICEY_LDS_MAX) K = h->n_inst >= 4 * ncu ? 4 : (h->n_inst >= 2 * ncu ? 2 : 1);
+  }
   if (K > h->n_inst) K = 1;
   h->lds = want_lds && spicey_lds_bytes(P, K, true) <= SPICEY_LDS_MAX;
-  if (!h->lds && want_lds && K > 1) {
-    K = 1;
-    h->lds = spicey_lds_bytes(P, 1, true) <= SPICEY_LDS_MAX;
+  if (!h->lds && want_lds && K > 1 && spicey_lds_bytes(P, 1, true) <= SPICEY_LDS_MAX) {
+    K = 1;  // one instance fits LDS where K interleaved ones do not: LDS wins
+    h->lds = true;
   }
   h->K = K;
   // interpreter: v2 needs the LDS workspace, 16-bit records and K <= 2

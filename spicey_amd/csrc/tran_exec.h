@@ -38,6 +38,9 @@
 #define SPICEY_OPAQUE_S(x) asm volatile("" : "+s"(x))
 // wave vote: true if the condition holds in any active lane (a scalar branch: whole waves skip work nobody needs)
 #define SPICEY_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+// result streams are written once and never read by the kernel: non-temporal stores keep them from evicting the
+// L2-resident program / parameter lines
+#define SPICEY_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #define SPICEY_NOUNROLL _Pragma("unroll 1")  // thread-strided loops run 1-2 trips: unrolling only costs VGPRs
 #define SPICEY_SCHED_FENCE __builtin_amdgcn_sched_barrier(0)  // keep the K instances' code from being interleaved
 #else
@@ -47,6 +50,7 @@
 #define SPICEY_OPAQUE(x) (void)(x)
 #define SPICEY_OPAQUE_S(x) (void)(x)
 #define SPICEY_WAVE_ANY(c) true
+#define SPICEY_STREAM_STORE(ptr, val) (*(ptr) = (val))
 #endif
 
 // phase tags (profiling slots, SpiceyRun::prof)
@@ -790,7 +794,7 @@ struct TranPhases2 {
   SPICEY_HD void z_cap(int i, uint32_t ab, int k, size_t in, const double *g, double *oi, int cC, double &vprev, bool last) const {
     const double dv = dv16(ab, k);
     const double gc = g[P.nR + i];
-    if (oi) oi[cC + i] = gc * (dv - vprev);
+    if (oi) SPICEY_STREAM_STORE(&oi[cC + i], gc * (dv - vprev));
     vprev = dv;
     c.u[(size_t)i * K + k] = gc * dv;
     if (last) R.C_vprev[in * P.nC + i] = dv;
@@ -800,7 +804,7 @@ struct TranPhases2 {
     const double *dp = R.dpar + (in * P.nD + i) * 2;
     double gg, q, irec;
     spicey_diode_k(vd, R.D_is[in * P.nD + i], dp[0], dp[1], oi != nullptr, gg, q, irec);
-    if (oi) oi[cD + i] = irec;
+    if (oi) SPICEY_STREAM_STORE(&oi[cD + i], irec);
     c.gd[(size_t)(P.nS + i) * K + k] = gg;
     c.u[(size_t)(oD + i) * K + k] = q;
     if (last) R.D_vdprev[in * P.nD + i] = vd;
@@ -823,9 +827,9 @@ struct TranPhases2 {
         const int i = tid + j * T;
         uint32_t eR = rr.eR[j], eC = rr.eC[j], eD = rr.eD[j], ox = rr.ox[j];
         SPICEY_OPAQUE(eR); SPICEY_OPAQUE(eC); SPICEY_OPAQUE(eD); SPICEY_OPAQUE(ox);
-        if (i < P.nOut) ov[i] = volt16(ox, k);
+        if (i < P.nOut) SPICEY_STREAM_STORE(&ov[i], volt16(ox, k));
         SPICEY_SCHED_FENCE;
-        if (oi && i < P.nR) oi[cR + i] = dv16(eR, k) * g[i];
+        if (oi && i < P.nR) SPICEY_STREAM_STORE(&oi[cR + i], dv16(eR, k) * g[i]);
         SPICEY_SCHED_FENCE;
         if (i < P.nC) {
           double vp = K == 1 ? rr.vprev[j][0] : (k == 0 ? rr.vprev[j][0] : rr.vprev[j][K - 1]);

@@ -211,6 +211,22 @@ def test_large_instance_global_workspace(oracle_backend):
     assert tol_ratio(got["out_i"], ref["out_i"]).max() <= 1.0
 
 
+def test_config5_full_size_mesh(oracle_backend):
+    """BASELINE configs[4] at FULL size: rcd_mesh(100x100), 10 001 unknowns, nnz(L+U) = 355 387, 297 levels — three
+    timesteps against the oracle (the dense-GE restatement needs ~6 s per step at this size)."""
+    from spicey_amd.lib import HipBackend
+    ckt = parseNetlist(synth.rcd_mesh(100, seed=3, tran=".tran 1e-6 2e-6"))
+    flat = abi.flatten(ckt)
+    assert (flat.nR, flat.nC, flat.nV) == (19800, 9999, 1) and flat.n_var == 10001
+    src = abi.source_table(ckt, 1e-6, 2)
+    be = HipBackend()
+    got = be.run(flat, 2, 1e-6, src, want_currents=True)
+    assert got["status"] == 0 and be.info["nnz_a"] == 49602
+    ref = oracle_backend.run(flat, 2, 1e-6, src, want_currents=True)
+    assert tol_ratio(got["out_v"], ref["out_v"]).max() <= 1.0
+    assert tol_ratio(got["out_i"], ref["out_i"]).max() <= 1.0
+
+
 def test_degenerate_shapes(oracle_backend):
     """No capacitors / no diodes / single unknown / odd instance count with two instances per workgroup."""
     from spicey_amd.lib import HipBackend
