@@ -104,19 +104,53 @@ def simulate(netlist_text: str, backend=None) -> dict:
 
 
 def formatTranResult(tran: Optional[dict]) -> str:
-    """/root/reference/lib/formatting/formatTranResult.ts:1-23 (toPrecision(6) CSV)."""
+    """/root/reference/lib/formatting/formatTranResult.ts:1-23 (toPrecision(6) CSV), straight from the typed
+    result arrays: every column is formatted with one vectorised pass (SURVEY.md §8(f) rank 3 — after the solve is
+    fast, per-value string formatting dominates end-to-end time for large runs)."""
     if not tran:
         return "No TRAN analysis.\n"
     nodes = list(tran["nodeVoltages"].keys())
-    lines = [", ".join(["t(s)"] + [f"{n}:V" for n in nodes])]
-    for k, t in enumerate(tran["times"]):
-        row = [_to_precision6(t)]
-        for n in nodes:
-            series = tran["nodeVoltages"][n]
-            if k < len(series):
-                row.append(_to_precision6(float(series[k])))
-        lines.append(", ".join(row))
+    n = len(tran["times"])
+    cols = [_to_precision6_array(np.asarray(tran["times"], dtype=np.float64))]
+    for name in nodes:
+        series = np.asarray(tran["nodeVoltages"][name], dtype=np.float64)
+        col = _to_precision6_array(series[:n])
+        if len(col) < n:  # the reference skips missing values (`if (value == null) continue`)
+            col = np.concatenate([col, np.full(n - len(col), None, dtype=object)])
+        cols.append(col)
+    lines = [", ".join(["t(s)"] + [f"{nm}:V" for nm in nodes])]
+    for k in range(n):
+        lines.append(", ".join(c[k] for c in cols if c[k] is not None))
     return "\n".join(lines)
+
+
+def _to_precision6_array(x: np.ndarray) -> np.ndarray:
+    """Number.prototype.toPrecision(6) for a whole array (object array of str)."""
+    x = np.asarray(x, dtype=np.float64)
+    out = np.empty(x.shape, dtype=object)
+    finite = np.isfinite(x)
+    zero = finite & (x == 0)
+    out[zero] = "0.00000"
+    out[np.isnan(x)] = "NaN"
+    out[np.isposinf(x)] = "Infinity"
+    out[np.isneginf(x)] = "-Infinity"
+    nz = finite & ~zero
+    if nz.any():
+        v = x[nz]
+        sci = np.char.mod("%.5e", v)  # d.ddddde+XX, correctly rounded to 6 significant digits
+        mant = np.char.partition(sci, "e")
+        e = mant[:, 2].astype(np.int64)
+        res = np.empty(v.shape, dtype=object)
+        big = (e < -6) | (e >= 6)
+        if big.any():
+            sign = np.where(e[big] >= 0, "+", "-")
+            res[big] = [f"{m}e{s}{abs(int(k))}" for m, s, k in zip(mant[big, 0], sign, e[big])]
+        for dec in range(0, 12):  # fixed notation: 5 - e decimals
+            sel = ~big & (np.maximum(0, 5 - e) == dec)
+            if sel.any():
+                res[sel] = np.char.mod(f"%.{dec}f", v[sel])
+        out[nz] = res
+    return out
 
 
 def _to_precision6(x: float) -> str:

@@ -157,3 +157,22 @@ extern "C" int32_t spicey_emul_symbolic(const SpiceyDesc *d, int32_t *cpos, int3
   if (products) { products[0] = hp.n_products; products[1] = hp.n_bk_products; }
   return hp.structurally_singular ? SPICEY_ERR_SINGULAR : SPICEY_OK;
 }
+
+// Resident-layout introspection for structural tests: phase of every (wave, slot), per-phase counts and tail.
+extern "C" int32_t spicey_emul_resident(const SpiceyDesc *d, int32_t T, int32_t rmax, int32_t max_tail, int32_t *res_phase /*[T/64][rmax]*/,
+                                        uint32_t *res_valid /*[rmax][T] 1 if the slot holds a task*/, uint32_t *ph_cnt /*[2L]*/,
+                                        uint32_t *st_cnt /*[2L]*/, int32_t *meta /*[4]: nLevels, tail_first, tail_n, has16*/) {
+  HostProgram hp;
+  std::string err;
+  int32_t rc = spicey_build_program(d, hp, err);
+  if (rc != SPICEY_OK) return rc;
+  HostResident hr;
+  spicey_build_resident(hp, T, rmax, hr, max_tail);
+  const int nPh = (int)hp.ph_cnt.size();
+  memcpy(res_phase, hr.res_phase.data(), sizeof(int32_t) * hr.res_phase.size());
+  for (int s = 0; s < rmax; s++)
+    for (int t = 0; t < T; t++) res_valid[(size_t)s * T + t] = (hr.res[((size_t)s * T + t) * 4] >> 16 & (SPICEY_R16_VALID << 8)) ? 1u : 0u;
+  for (int p = 0; p < nPh; p++) { ph_cnt[p] = hp.ph_cnt[p]; st_cnt[p] = hr.st_cnt[p]; }
+  meta[0] = hp.hdr.nLevels; meta[1] = hr.tail_first; meta[2] = hr.tail_n; meta[3] = hp.hdr.has16;
+  return SPICEY_OK;
+}

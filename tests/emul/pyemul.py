@@ -24,6 +24,9 @@ def lib():
                                       i32p, f64p, f64p, f64p, i32p, C.c_int32, C.POINTER(abi.SpiceyInfo), i32p, i64p, C.c_int32]
         L.spicey_emul_symbolic.restype = C.c_int32
         L.spicey_emul_symbolic.argtypes = [C.POINTER(abi.SpiceyDesc), i32p, i32p, i32p, C.POINTER(abi.SpiceyInfo), i64p]
+        L.spicey_emul_resident.restype = C.c_int32
+        L.spicey_emul_resident.argtypes = [C.POINTER(abi.SpiceyDesc), C.c_int32, C.c_int32, C.c_int32, i32p, C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), i32p]
         _LIB = L
     return _LIB
 
@@ -73,3 +76,18 @@ def symbolic(flat: abi.FlatCircuit):
     rc = L.spicey_emul_symbolic(C.byref(d), _p(cpos, C.c_int32), _p(rpos, C.c_int32), _p(level, C.c_int32), C.byref(info),
                                 _p(prods, C.c_int64))
     return rc, cpos, rpos, level, info.as_dict(), prods
+
+
+def resident_layout(flat: abi.FlatCircuit, T: int, rmax: int, max_tail: int):
+    L = lib()
+    d = flat.desc()
+    rc, _, _, level, info, _ = symbolic(flat)
+    nph = 2 * info["n_levels"]
+    res_phase = np.zeros((T // 64, rmax), np.int32)
+    res_valid = np.zeros((rmax, T), np.uint32)
+    ph_cnt = np.zeros(nph, np.uint32)
+    st_cnt = np.zeros(nph, np.uint32)
+    meta = np.zeros(4, np.int32)
+    rc = L.spicey_emul_resident(C.byref(d), T, rmax, max_tail, _p(res_phase, C.c_int32), _p(res_valid, C.c_uint32), _p(ph_cnt, C.c_uint32),
+                                _p(st_cnt, C.c_uint32), _p(meta, C.c_int32))
+    return rc, res_phase, res_valid, ph_cnt, st_cnt, meta

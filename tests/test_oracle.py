@@ -133,3 +133,14 @@ def test_timestep_rounding():
         dt, steps = abi.computeEffectiveTimeStep(dt_req, tstop)
         assert steps == want, (dt_req, tstop, steps)
         assert pyoracle.timestep(dt_req, tstop) == (dt, steps)
+
+
+def test_format_tran_result_vectorised_matches_scalar():
+    """formatTranResult from typed arrays (vectorised toPrecision(6)) equals the scalar definition value by value."""
+    from spicey_amd.simulate import _to_precision6, _to_precision6_array
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.standard_normal(2000) * 10.0 ** rng.integers(-12, 12, 2000), [0.0, -0.0, 1e-7, 9.999995, 999999.5, 1e21,
+                        123456.5, 0.000001, 5e-324, np.inf, -np.inf, np.nan, 4.9999995e-5, 1e5, 99999.95]])
+    got = _to_precision6_array(x)
+    for v, g in zip(x, got):
+        assert g == _to_precision6(float(v)), (v, g, _to_precision6(float(v)))

