@@ -89,6 +89,7 @@ typedef struct SpiceyOptions {
   int32_t geometry;      /* v2 only. 0 auto; 1 = latency: one workgroup per CU, whole program in registers;
                             2 = throughput: two 512-thread workgroups per CU (<= 128 VGPRs, wide levels streamed) */
   int32_t debug;         /* diagnostics: bit 0 = no tail merge; bits 8.. = extra empty phases per solve */
+  int32_t wgs_per_inst;  /* global-workspace path: workgroups (CUs) cooperating on one instance; 0 auto, 1 = none */
 } SpiceyOptions;
 
 typedef struct SpiceyInfo {
@@ -105,6 +106,7 @@ typedef struct SpiceyInfo {
   int32_t interpreter;      /* 1 or 2, see SpiceyOptions */
   int32_t geometry;         /* 1 or 2 (v2), see SpiceyOptions */
   int32_t tail_levels;      /* v2: elimination-tree levels merged into the single-wave tail phase */
+  int32_t wgs_per_inst;     /* workgroups cooperating on one instance (group mode), else 1 */
   int32_t resident_slots;   /* v2: 16-byte task records per thread kept in VGPRs */
   int64_t resident_tasks;   /* v2: factor/backward tasks held in registers */
   int64_t streamed_tasks;   /* v2: tasks still fetched from L2 every step */

@@ -37,14 +37,14 @@ class SpiceyDesc(C.Structure):
 
 class SpiceyOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("threads", C.c_int32), ("inst_per_wg", C.c_int32),
-                ("want_currents", C.c_int32), ("force_global", C.c_int32), ("profile", C.c_int32), ("interpreter", C.c_int32), ("geometry", C.c_int32), ("debug", C.c_int32)]
+                ("want_currents", C.c_int32), ("force_global", C.c_int32), ("profile", C.c_int32), ("interpreter", C.c_int32), ("geometry", C.c_int32), ("debug", C.c_int32), ("wgs_per_inst", C.c_int32)]
 
 
 class SpiceyInfo(C.Structure):
     _fields_ = [("n_var", C.c_int32), ("nnz_a", C.c_int32), ("nnz_lu", C.c_int32), ("n_levels", C.c_int32),
                 ("threads", C.c_int32), ("inst_per_wg", C.c_int32), ("lds_bytes", C.c_int32), ("n_cur", C.c_int32),
                 ("n_out", C.c_int32), ("n_workgroups", C.c_int32), ("interpreter", C.c_int32), ("geometry", C.c_int32),
-                ("tail_levels", C.c_int32), ("resident_slots", C.c_int32),
+                ("tail_levels", C.c_int32), ("wgs_per_inst", C.c_int32), ("resident_slots", C.c_int32),
                 ("resident_tasks", C.c_int64), ("streamed_tasks", C.c_int64), ("program_bytes", C.c_int64),
                 ("algorithmic_bytes_solve", C.c_int64)]
 

@@ -19,6 +19,7 @@ namespace {
 struct GpuExec {
   unsigned long long *prof;  // null unless phase profiling was requested
   __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
+  __device__ __forceinline__ bool failed() const { return false; }
   template <class F>
   __device__ __forceinline__ void phase(int tag, F f) {
     long long t0 = 0;
@@ -62,6 +63,74 @@ __global__ void __launch_bounds__(1024) spicey_tran_kernel(SpiceyProg P, SpiceyR
   }
   GpuExec ex{R.prof ? R.prof + (size_t)wg * SPICEY_PH_SLOTS : nullptr};
   spicey_tran_run<K>(ex, P, R, c, wg);
+}
+
+// Group mode: G workgroups (G CUs) cooperate on ONE large instance whose workspace lives in global memory / L2.
+// A phase is the same body run by G*blockDim threads, followed by a barrier across the G workgroups: every storing
+// wave drains its stores, the workgroup barriers, lane 0 releases at agent scope and bumps a monotonic counter, polls
+// it relaxed, then acquires at agent scope before the workgroup's threads read what the others wrote (cdna guide
+// Guideline 16).  All G workgroups are co-resident by construction (the host launches at most one per CU) and every
+// spin is bounded: on a timeout the abort word is set, every workgroup leaves, and the run reports an error.
+struct GpuGroupExec {
+  int G, wgi;
+  unsigned int *counter, *abortf;
+  unsigned int epoch;
+  bool bad;
+  __device__ __forceinline__ int threads() const { return G * (int)blockDim.x; }
+  __device__ __forceinline__ bool failed() const { return bad; }
+  __device__ __forceinline__ void barrier() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    epoch++;
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int target = epoch * (unsigned int)G;
+      unsigned int spins = 0;
+      while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > (1u << 22) || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) bad = true;
+  }
+  template <class F>
+  __device__ __forceinline__ void phase(int, F f) {
+    int tid = wgi * (int)blockDim.x + (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    f(tid);
+    barrier();
+  }
+};
+
+template <int K>
+__global__ void __launch_bounds__(1024) spicey_tran_kernel_grp(SpiceyProg P, SpiceyRun R) {
+  WgCtx<K> c;
+  const int G = R.wgs_per_group;
+  const int grp = (int)blockIdx.x / G, wgi = (int)blockIdx.x % G;
+  const size_t nW = (size_t)P.nW * K, nU = (size_t)P.nU * K, nG = (size_t)P.nGdyn * K;
+  const size_t stride = nW + nU + nG + (((size_t)P.nS * K + 1) >> 1);
+  c.W = R.gW + (size_t)grp * stride;
+  c.u = c.W + nW;
+  c.gd = c.u + nU;
+  c.ison = (int32_t *)(c.gd + nG);
+  c.flags = R.grp_flags + (size_t)grp * 4;
+  c.tail = nullptr;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int in = grp * K + k;
+    c.valid[k] = in < R.n_inst;
+    c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
+  }
+  GpuGroupExec ex{G, wgi, R.grp_sync + (size_t)grp * 4, R.grp_sync + (size_t)grp * 4 + 1, 0u, false};
+  spicey_tran_run<K>(ex, P, R, c, grp);
 }
 
 // v2: register-resident program (LDS workspace only; 16-bit records)
@@ -184,6 +253,16 @@ size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds, int tail_n) {
 
 size_t spicey_gw_doubles_per_wg(const SpiceyProg &P, int K) {
   return ((size_t)P.nW + P.nU + P.nGdyn) * K + (((size_t)P.nS * K + 1) >> 1);
+}
+
+hipError_t spicey_launch_tran_grp(const SpiceyProg &P, const SpiceyRun &R, int K, int n_groups, int threads, hipStream_t st) {
+  const int grid = n_groups * R.wgs_per_group;
+  switch (K) {
+    case 1: hipLaunchKernelGGL(spicey_tran_kernel_grp<1>, dim3(grid), dim3(threads), 0, st, P, R); break;
+    case 2: hipLaunchKernelGGL(spicey_tran_kernel_grp<2>, dim3(grid), dim3(threads), 0, st, P, R); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bool lds, int grid, int threads, hipStream_t st) {

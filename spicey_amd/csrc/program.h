@@ -70,13 +70,14 @@ struct SpiceyProg {
   const uint32_t *upd_pairs;    // per slice: [len][3][64]  (L entry, pivot diagonal, U entry)
   int32_t nUpdSlices;
 
-  // --- backward substitution: per level (executed top level first)
+  // --- backward substitution, column-oriented (v1): per level (executed top level first) the rows below get
+  //     y[r] -= (y[k] * dinv[k]) * U[r][k]; same slice format as the factor tasks; then x[i] = y[i] * W[bk_d[i]]
   const uint32_t *bk_lvl_slice; // [nLevels+1]
   const SpiceySlice *bk_slice;  // [nBkSlices]
-  const uint32_t *bk_x;         // [nBkSlices*64] W index of x'[k], or SPICEY_TGT_PAD
-  const uint32_t *bk_d;         // [nBkSlices*64] W index of the pivot's (reciprocal) diagonal
+  const uint32_t *bk_x;         // [nBkSlices*64] W index of y[r], or SPICEY_TGT_PAD
+  const uint32_t *bk_d;         // [n] W index of pivot i's (reciprocal) diagonal
   const uint32_t *bk_cnt;       // [nBkSlices*64]
-  const uint32_t *bk_pairs;     // per slice: [len][2][64]  (U entry, W index of x'[b])
+  const uint32_t *bk_pairs;     // per slice: [len][3][64]  (y[k], dinv[k], U[r][k])
   int32_t nBkSlices;
 
   // --- compact 16-bit task records (LDS path: nW < 65536 always holds there) ---------------------
@@ -161,5 +162,10 @@ struct SpiceyRun {
   // status: [n_workgroups][4] = {code, inst, step, iter}; solve counts [n_workgroups]
   int32_t *status;
   unsigned long long *solves;
+  // multi-workgroup-per-instance mode (large circuits): [n_groups][4] = {barrier counter, abort flag, -, -}, zeroed
+  // before every launch, and [n_groups][4] int32 flags (the WgCtx flags live in global memory there)
+  unsigned int *grp_sync;
+  int32_t *grp_flags;
+  int32_t wgs_per_group;
   unsigned long long *prof;  // optional [n_workgroups][SPICEY_PH_SLOTS] shader-clock cycles per phase kind (diagnostics)
 };

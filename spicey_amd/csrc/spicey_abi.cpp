@@ -21,6 +21,9 @@ struct SpiceyHandle {
   SpiceyResident dres{};
   int interp = 1;
   bool packed = false;  // two 512-thread workgroups per CU
+  int G = 1;            // workgroups per instance group (group mode: global workspace only)
+  unsigned int *d_gsync = nullptr;
+  int32_t *d_gflags = nullptr;
   void *d_res = nullptr;
   SpiceyOptions opt{};
   int n_inst = 0, n_nodes = 0;
@@ -77,7 +80,7 @@ extern "C" void spicey_destroy(SpiceyHandle *h) {
   if (!h) return;
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
   void *ptrs[] = {h->d_res, h->d_blob, h->d_R, h->d_C, h->d_L, h->d_Sron, h->d_Sroff, h->d_Svon, h->d_Svoff, h->d_Dis, h->d_Dn, h->d_Cv,
-                  h->d_Li, h->d_Dv, h->d_Son, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_status, h->d_solves, h->d_prof};
+                  h->d_Li, h->d_Dv, h->d_Son, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_gsync, h->d_gflags, h->d_status, h->d_solves, h->d_prof};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -235,8 +238,26 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   if ((rc = upload(h, &h->d_statv, nodbl, ni * P.nLU)) != SPICEY_OK) return fail(rc);
   if ((rc = upload(h, &h->d_rcoef, nodbl, ni * (size_t)(P.nRhsIdx + 1))) != SPICEY_OK) return fail(rc);
   if ((rc = upload(h, &h->d_dpar, nodbl, ni * (size_t)P.nD * 2)) != SPICEY_OK) return fail(rc);
-  if (!h->lds)
+  if (!h->lds) {
     if ((rc = upload(h, &h->d_gW, nodbl, (size_t)h->grid * spicey_gw_doubles_per_wg(P, K))) != SPICEY_OK) return fail(rc);
+    // group mode: several CUs per instance when the batch leaves CUs idle and the circuit is large enough for the
+    // cross-workgroup barrier (~3 us per phase) to pay; all workgroups must be co-resident: grid * G <= #CU
+    int G = h->opt.wgs_per_inst;
+    if (G < 0 || G > 64 || (G > 1 && K > 2)) { h->err = "wgs_per_inst must be in [0, 64] (and inst_per_wg <= 2 with it)"; return fail(SPICEY_ERR_BAD_DESC); }
+    if (G == 0) {
+      G = 1;
+      if (K <= 2 && P.nLU >= 40000)
+        while (G * 2 <= 16 && h->grid * G * 2 <= ncu) G *= 2;
+    }
+    if (h->grid * G > ncu) G = std::max(1, ncu / h->grid);
+    h->G = G;
+    if (G > 1) {
+      const unsigned int *nou = nullptr;
+      if ((rc = upload(h, &h->d_gsync, nou, (size_t)h->grid * 4)) != SPICEY_OK) return fail(rc);
+      const int32_t *noi = nullptr;
+      if ((rc = upload(h, &h->d_gflags, noi, (size_t)h->grid * 4)) != SPICEY_OK) return fail(rc);
+    }
+  }
   const int32_t *noint = nullptr;
   if ((rc = upload(h, &h->d_status, noint, (size_t)h->grid * 4)) != SPICEY_OK) return fail(rc);
   const unsigned long long *noull = nullptr;
@@ -267,6 +288,7 @@ extern "C" int32_t spicey_get_info(SpiceyHandle *h, SpiceyInfo *info) {
   info->interpreter = h->interp;
   info->geometry = h->interp == 2 ? (h->packed ? 2 : 1) : 0;
   info->tail_levels = h->hres.tail_n;
+  info->wgs_per_inst = h->G;
   info->resident_slots = h->interp == 2 ? h->hres.rmax : 0;
   info->resident_tasks = h->hres.resident_tasks;
   info->streamed_tasks = h->hres.streamed_tasks;
@@ -300,8 +322,17 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   R.status = h->d_status; R.solves = h->d_solves; R.prof = h->d_prof;
   if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, (size_t)h->grid * 72 * sizeof(unsigned long long), st));
   HIPCHK(h, hipEventRecord(h->ev0, st));
-  if (h->interp == 2) HIPCHK(h, spicey_launch_tran_v2(h->dprog, h->dres, R, h->K, h->grid, h->T, st, h->packed));
-  else HIPCHK(h, spicey_launch_tran(h->dprog, R, h->K, h->lds, h->grid, h->T, st));
+  R.wgs_per_group = h->G;
+  R.grp_sync = h->d_gsync;
+  R.grp_flags = h->d_gflags;
+  if (h->interp == 2) {
+    HIPCHK(h, spicey_launch_tran_v2(h->dprog, h->dres, R, h->K, h->grid, h->T, st, h->packed));
+  } else if (h->G > 1) {
+    HIPCHK(h, hipMemsetAsync(h->d_gsync, 0, (size_t)h->grid * 4 * sizeof(unsigned int), st));
+    HIPCHK(h, spicey_launch_tran_grp(h->dprog, R, h->K, h->grid, h->T, st));
+  } else {
+    HIPCHK(h, spicey_launch_tran(h->dprog, R, h->K, h->lds, h->grid, h->T, st));
+  }
   HIPCHK(h, hipEventRecord(h->ev1, st));
   h->pending = true;
   h->last_stream = st;
@@ -326,6 +357,10 @@ extern "C" int32_t spicey_sync(SpiceyHandle *h) {
   int best = -1;
   for (int g = 0; g < h->grid; g++)
     if (status[(size_t)g * 4] != 0 && (best < 0 || status[(size_t)g * 4 + 2] < status[(size_t)best * 4 + 2])) best = g;
+  if (best >= 0 && status[(size_t)best * 4] == 3) {
+    h->err = "cross-workgroup barrier timed out (group mode)";
+    return SPICEY_ERR_HIP;
+  }
   if (best >= 0) {
     char buf[160];
     snprintf(buf, sizeof(buf), "singular at inst %d step %d iter %d", status[(size_t)best * 4 + 1], status[(size_t)best * 4 + 2],

@@ -628,24 +628,40 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
   }
   hp.hdr.nUpdSlices = (int32_t)hp.upd_slice.size();
 
-  // ---- 5c. backward substitution tasks per level -------------------------------------------------
+  // ---- 5c. backward substitution, v1 (32-bit) form: COLUMN-oriented -----------------------------------
+  // x[k] = (y[k] - sum_b U[k][b] x[b]) / U[k][k] row by row means one thread walks a pivot's whole row; on a
+  // mesh the top separator rows have > 100 entries and that serial walk dominated the step.  Instead, level by
+  // level from the top, every row r below receives  y[r] -= U[r][k] * (y[k] * dinv[k])  from the pivots k of the
+  // level (gather by target row: short lists, wide parallelism, the same 3-operand task as the factor levels);
+  // one final phase scales x[i] = y[i] * dinv[i].  (The 16-bit records of the LDS path stay row-oriented: on
+  // circuits that fit LDS the rows are short and one phase fewer matters more.)
   hp.bk_lvl_slice.assign(1, 0);
   hp.bk_slice.clear(); hp.bk_x.clear(); hp.bk_d.clear(); hp.bk_cnt.clear(); hp.bk_pairs.clear();
   hp.n_bk_products = 0;
   for (int l = 0; l < nLevels; l++) {
+    struct Prod { uint32_t tgt, l, d, u; };
+    std::vector<Prod> prods;
+    for (int k : by_level[l])
+      for (int p = E.ptr[k]; p < E.ptr[k + 1]; p++) {
+        const int r = E.col[p];
+        if (r >= k) break;  // columns of row k left of the diagonal = rows r with U[r][k] != 0
+        prods.push_back({(uint32_t)(nLU + r), (uint32_t)(nLU + k), (uint32_t)diag[k], (uint32_t)E.find(r, k)});
+      }
+    std::stable_sort(prods.begin(), prods.end(), [](const Prod &x, const Prod &y) { return x.tgt < y.tgt; });
     std::vector<std::pair<uint32_t, std::vector<uint32_t>>> tasks;
-    std::vector<uint32_t> dd;
-    for (int k : by_level[l]) {
+    for (size_t i = 0; i < prods.size();) {
+      size_t j = i;
       std::vector<uint32_t> flat;
-      for (int b : upper[k]) { flat.push_back((uint32_t)E.find(k, b)); flat.push_back((uint32_t)(nLU + b)); }
-      hp.n_bk_products += (int64_t)upper[k].size();
-      tasks.emplace_back((uint32_t)(nLU + k), std::move(flat));
-      dd.push_back((uint32_t)diag[k]);
+      while (j < prods.size() && prods[j].tgt == prods[i].tgt) { flat.push_back(prods[j].l); flat.push_back(prods[j].d); flat.push_back(prods[j].u); j++; }
+      tasks.emplace_back(prods[i].tgt, std::move(flat));
+      i = j;
     }
-    pack_slices<2>(tasks, hp.bk_slice, hp.bk_x, hp.bk_cnt, hp.bk_pairs, &dd, &hp.bk_d);
+    hp.n_bk_products += (int64_t)prods.size();
+    pack_slices<3>(tasks, hp.bk_slice, hp.bk_x, hp.bk_cnt, hp.bk_pairs);
     hp.bk_lvl_slice.push_back((uint32_t)hp.bk_slice.size());
   }
   hp.hdr.nBkSlices = (int32_t)hp.bk_slice.size();
+  hp.bk_d.assign(diag.begin(), diag.end());  // [n]: entry id of every pivot's (reciprocal) diagonal
 
   // ---- 5c'. compact 16-bit records of the same tasks, phases in execution order -------------------
   hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear();

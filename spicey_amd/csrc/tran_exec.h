@@ -299,33 +299,33 @@ struct TranPhases {
     }
   }
 
-  // ---- K_l: backward substitution of one level --------------------------------------------------
+  // ---- K_l: backward substitution, column-oriented: the pivots of level l update the rows below them --------
   SPICEY_HD void k_level(int tid, int l) const {
     const int nw = T >> 6, w = tid >> 6, lane = tid & 63;
     for (uint32_t s = P.bk_lvl_slice[l] + w; s < P.bk_lvl_slice[l + 1]; s += nw) {
       const uint32_t t = s * 64 + lane;
-      const uint32_t xi = P.bk_x[t];
-      if (xi == SPICEY_TGT_PAD) continue;
-      const uint32_t cnt = P.bk_cnt[t], di = P.bk_d[t];
+      const uint32_t yi = P.bk_x[t];
+      if (yi == SPICEY_TGT_PAD) continue;
+      const uint32_t cnt = P.bk_cnt[t];
       const uint32_t off = P.bk_slice[s].off + lane;
       double acc[K];
-      for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)xi * K + k];
-      uint32_t j = 0;
-      for (; j + 4 <= cnt; j += 4) {
-        uint32_t ui[4], xb[4];
-        for (int q = 0; q < 4; q++) { ui[q] = P.bk_pairs[off + ((j + q) * 2 + 0) * 64]; xb[q] = P.bk_pairs[off + ((j + q) * 2 + 1) * 64]; }
-        double uv[4][K], xv[4][K];
-        for (int q = 0; q < 4; q++)
-          for (int k = 0; k < K; k++) { uv[q][k] = c.W[(size_t)ui[q] * K + k]; xv[q][k] = c.W[(size_t)xb[q] * K + k]; }
-        for (int q = 0; q < 4; q++)
-          for (int k = 0; k < K; k++) acc[k] = fma(-uv[q][k], xv[q][k], acc[k]);
+      for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)yi * K + k];
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t ki = P.bk_pairs[off + (j * 3 + 0) * 64];
+        const uint32_t di = P.bk_pairs[off + (j * 3 + 1) * 64];
+        const uint32_t ui = P.bk_pairs[off + (j * 3 + 2) * 64];
+        for (int k = 0; k < K; k++)
+          acc[k] = fma(-(c.W[(size_t)ki * K + k] * c.W[(size_t)di * K + k]), c.W[(size_t)ui * K + k], acc[k]);
       }
-      for (; j < cnt; j++) {
-        const uint32_t ui = P.bk_pairs[off + (j * 2 + 0) * 64];
-        const uint32_t xb = P.bk_pairs[off + (j * 2 + 1) * 64];
-        for (int k = 0; k < K; k++) acc[k] = fma(-c.W[(size_t)ui * K + k], c.W[(size_t)xb * K + k], acc[k]);
-      }
-      for (int k = 0; k < K; k++) c.W[(size_t)xi * K + k] = acc[k] * c.W[(size_t)di * K + k];
+      for (int k = 0; k < K; k++) c.W[(size_t)yi * K + k] = acc[k];
+    }
+  }
+  // x[i] = y[i] * dinv[i] for every unknown (after the last level)
+  SPICEY_HD void k_scale(int tid) const {
+    SPICEY_NOUNROLL
+    for (int i = tid; i < P.n; i += T) {
+      const uint32_t di = P.bk_d[i];
+      for (int k = 0; k < K; k++) c.W[(size_t)(P.nLU + i) * K + k] *= c.W[(size_t)di * K + k];
     }
   }
 
@@ -989,6 +989,7 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
   int32_t err_iter = 0;
   if (c.flags[1]) { code = 1; }
   for (int64_t step = 0; step <= R.steps && code == 0; step++) {
+    if (ex.failed()) { code = 3; err_step = step; break; }  // a cross-workgroup barrier timed out (group mode only)
     int iter = 0;
     for (;;) {
       ex.phase(SPICEY_PH_B, [&](int tid) { ph.b_stamp(tid); });
@@ -996,7 +997,11 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
         if (P.lvl_slice[l] == P.lvl_slice[l + 1]) continue;
         ex.phase(SPICEY_PH_U0 + (l < 31 ? l : 31), [&](int tid) { ph.u_level(tid, l); });
       }
-      for (int l = P.nLevels - 1; l >= 0; l--) ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) { ph.k_level(tid, l); });
+      for (int l = P.nLevels - 1; l >= 0; l--) {
+        if (P.bk_lvl_slice[l] == P.bk_lvl_slice[l + 1]) continue;
+        ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) { ph.k_level(tid, l); });
+      }
+      ex.phase(SPICEY_PH_K0, [&](int tid) { ph.k_scale(tid); });
       if (c.flags[1]) { code = 1; err_step = step; err_iter = iter; break; }
       if (P.nS == 0) break;
       ex.phase(SPICEY_PH_S, [&](int tid) { ph.s_switches(tid); });

@@ -20,6 +20,7 @@ struct SeqExec {
   bool reverse;
   void *rr = nullptr;  // per-thread "registers" of the v2 interpreter: std::vector<Regs>*
   int threads() const { return T; }
+  bool failed() const { return false; }
   template <class Regs>
   Regs &regs(int tid) {
     return (*static_cast<std::vector<Regs> *>(rr))[tid];

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Large-instance sanity probe: rcd_mesh(rows) on the GPU (v1 interpreter when the workspace exceeds LDS)."""
+"""Large-instance probe: rcd_mesh(rows) on the GPU (global workspace when L+U exceeds LDS), optionally with several
+workgroups cooperating on the instance (--wgs)."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,28 +12,30 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, nargs="+", default=[20, 32, 50])
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--check", type=int, default=1)
+ap.add_argument("--wgs", type=int, nargs="+", default=[0])
 args = ap.parse_args()
 for rows in args.rows:
     t0 = time.time()
     ckt = parseNetlist(synth.rcd_mesh(rows, seed=3, tran=f".tran 1e-6 {args.steps * 1e-6!r}"))
-    dt, steps = abi.computeEffectiveTimeStep(1e-6, args.steps * 1e-6)
     steps = args.steps
     flat = abi.flatten(ckt)
     src = abi.source_table(ckt, 1e-6, steps)
-    t1 = time.time()
-    h = Handle(flat)
-    t2 = time.time()
-    info = h.info()
-    r = h.run(steps, 1e-6, src, want_currents=True)
-    rec = dict(rows=rows, n=info["n_var"], nnz_a=info["nnz_a"], nnz_lu=info["nnz_lu"], levels=info["n_levels"], interp=info["interpreter"],
-               T=info["threads"], lds=info["lds_bytes"], program_MB=info["program_bytes"] / 1e6, parse_s=t1 - t0, create_s=t2 - t1,
-               status=r["status"], kernel_ms=r.get("kernel_ms"), ms_per_step=(r.get("kernel_ms") or 0) / (steps + 1),
-               resident=info["resident_tasks"], streamed=info["streamed_tasks"])
-    if args.check and r["status"] == 0 and info["n_var"] <= 2600:
-        from oracle.pyoracle import OracleBackend
-        s2 = min(steps, 5)
-        ref = OracleBackend().run(flat, s2, 1e-6, src[: s2 + 1], want_currents=False)
-        e = np.abs(r["out_v"][:, : s2 + 1] - ref["out_v"]) / (1e-9 * np.abs(ref["out_v"]) + 1e-12)
-        rec["err_over_tol"] = float(e.max())
-    print(json.dumps(rec), flush=True)
-    h.close()
+    ref = None
+    for G in args.wgs:
+        t1 = time.time()
+        h = Handle(flat, wgs_per_inst=G)
+        t2 = time.time()
+        info = h.info()
+        r = h.run(steps, 1e-6, src, want_currents=True)
+        rec = dict(rows=rows, n=info["n_var"], nnz_lu=info["nnz_lu"], levels=info["n_levels"], interp=info["interpreter"], T=info["threads"],
+                   G=info["wgs_per_inst"], lds=info["lds_bytes"], program_MB=info["program_bytes"] / 1e6, create_s=t2 - t1, status=r["status"],
+                   detail=r.get("detail"), ms_per_step=(r.get("kernel_ms") or 0) / (steps + 1))
+        if args.check and r["status"] == 0 and info["n_var"] <= 2600:
+            if ref is None:
+                from oracle.pyoracle import OracleBackend
+                s2 = min(steps, 5)
+                ref = OracleBackend().run(flat, s2, 1e-6, src[: s2 + 1], want_currents=False)
+            e = np.abs(r["out_v"][:, : ref["out_v"].shape[1]] - ref["out_v"]) / (1e-9 * np.abs(ref["out_v"]) + 1e-12)
+            rec["err_over_tol"] = float(e.max())
+        print(json.dumps(rec), flush=True)
+        h.close()
