@@ -201,18 +201,21 @@ __global__ void __launch_bounds__(MAXT, MINW) spicey_tran_kernel_v2(SpiceyProg P
   unsigned long long *lprof = (unsigned long long *)(smem + off_prof);
   c.tail = (uint32_t *)(smem + off_prof + SPICEY_PH_SLOTS * sizeof(unsigned long long));
   ex.prof = R.prof ? lprof : nullptr;
-  long long c0 = 0, w0 = 0;
+#if SPICEY_EXP & 64
+  c.zprof = R.prof ? lprof + 56 : nullptr;
+#endif
   if (R.prof) {
     for (int i = (int)threadIdx.x; i < SPICEY_PH_SLOTS; i += (int)blockDim.x) lprof[i] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) { c0 = clock64(); w0 = wall_clock64(); }
+    // start stamps wait in their own slots (not in registers: nothing may stay live around the whole run)
+    if (threadIdx.x == 0) { lprof[5] = (unsigned long long)clock64(); lprof[6] = (unsigned long long)wall_clock64(); }
   }
   spicey_tran_run_v2<K, RMAX, NSV, NEL>(ex, P, Q, R, c, wg);
   if (R.prof) {
     __syncthreads();
     if (threadIdx.x == 0) {  // slots 5/6: whole-run shader cycles and 100 MHz wall ticks -> effective clock
-      lprof[5] = (unsigned long long)(clock64() - c0);
-      lprof[6] = (unsigned long long)(wall_clock64() - w0);
+      lprof[5] = (unsigned long long)clock64() - lprof[5];
+      lprof[6] = (unsigned long long)wall_clock64() - lprof[6];
     }
     __syncthreads();
     for (int i = (int)threadIdx.x; i < SPICEY_PH_SLOTS; i += (int)blockDim.x) R.prof[(size_t)wg * SPICEY_PH_SLOTS + i] = lprof[i];

@@ -398,7 +398,7 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
 
   hp.hdr = SpiceyProg{};
   hp.hdr.n = n; hp.hdr.nR = nR; hp.hdr.nC = nC; hp.hdr.nL = nL; hp.hdr.nV = nV; hp.hdr.nS = nS; hp.hdr.nD = nD;
-  hp.hdr.nU = nC + nL + nV + nD; hp.hdr.nGdyn = nS + nD; hp.hdr.nGstat = nR + nC + nL + 1;
+  hp.hdr.nU = nC + nL + nV + nD + nV;  /* + one slot per source for the NEXT step's value (v2, written during the last backward phase) */ hp.hdr.nGdyn = nS + nD; hp.hdr.nGstat = nR + nC + nL + 1;
   hp.hdr.nOut = nOut; hp.hdr.nCur = nR + nC + nL + nV + nS + nD;
 
   // ---- 2. zero-free diagonal ------------------------------------------------------------------

@@ -28,6 +28,17 @@
 #else
 #define SPICEY_HD inline
 #endif
+#ifndef SPICEY_EXP
+#define SPICEY_EXP 0  // timing experiments only (tools/exp_build.sh): bit0 no result stores, bit1 no diode section, bit2 no capacitor section, bit3 no parameter loads, bit4 no voltage / resistor section, bit5 no remainder loops
+#endif
+#ifndef SPICEY_MARK_TID
+#define SPICEY_MARK_TID 0
+#endif
+#if (SPICEY_EXP & 64) && defined(__HIP_DEVICE_COMPILE__)
+#define SPICEY_MARK(c, n) do { if ((c).zprof && threadIdx.x == (SPICEY_MARK_TID)) { unsigned long long t_ = clock64(); if ((n) < 15) (c).zprof[n] += t_ - (c).zprof[15]; (c).zprof[15] = t_; } } while (0)
+#else
+#define SPICEY_MARK(c, n) do { } while (0)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SPICEY_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)  // value is wave-uniform by construction
 // Keeps a register-resident packed word packed: without this hipcc hoists the field decode (8+ VGPRs and
@@ -40,7 +51,11 @@
 #define SPICEY_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
 // result streams are written once and never read by the kernel: non-temporal stores keep them from evicting the
 // L2-resident program / parameter lines
+#if SPICEY_EXP & 1
+#define SPICEY_STREAM_STORE(ptr, val) do { if ((val) == 1.2345e-300) __builtin_nontemporal_store((val), (ptr)); } while (0)
+#else
 #define SPICEY_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
 #define SPICEY_NOUNROLL _Pragma("unroll 1")  // thread-strided loops run 1-2 trips: unrolling only costs VGPRs
 #define SPICEY_SCHED_FENCE __builtin_amdgcn_sched_barrier(0)  // keep the K instances' code from being interleaved
 #else
@@ -71,6 +86,9 @@ struct WgCtx {
   int32_t *ison; // [nS][K]
   int32_t *flags;  // [0] switched, [1] singular code, [2] singular inst
   uint32_t *tail;  // [tail_n][64][4] task records of the tail phases (v2), or null
+#if SPICEY_EXP & 64
+  unsigned long long *zprof;  // experiment builds: 16 profiling slots for marks inside B / Z ([15] = last timestamp)
+#endif
   int32_t inst[K];
   int32_t valid[K];
 };
@@ -451,11 +469,17 @@ struct ResRegs {
   typename U32Vec<RMAX>::type w0, w1, w2, w3;
   typename U32Vec<RMAX / 4>::type phv;
   int32_t cursor;
+  // entries with dynamic stamps are numbered first: only the first NDD slots can hold one and need a descriptor
+  static constexpr int NDD = NSV == 6 ? 2 : NSV / 2;
   double sv[NSV][K];    // static part of the entries this thread re-stamps (e = tid + j T)
-  uint32_t dd[NSV];     // their dynamic-stamp descriptors
+  uint32_t dd[NDD];     // dynamic-stamp descriptors of the first NDD of them
   uint32_t rhs[NEL][2]; // right-hand-side descriptors of rows tid + j T
-  uint32_t eR[NEL], eC[NEL], eL[NEL], eD[NEL], ox[NEL];  // packed terminals of elements tid + j T; W index of output tid + j T
+  uint32_t eR[NEL], eC[NEL], eD[NEL], ox[NEL];  // packed terminals of elements tid + j T; W index of output tid + j T (ox[0] >> 16: source tid's branch current)
   double vprev[NEL][K]; // vPrev of capacitors tid + j T (simulateTRAN.ts:221-225), exact
+  // Z's element parameters {1/R, C/dt, Is, 1/(N VT), Is/(N VT)} of items tid + j T and the next source value:
+  // fetched at the end of the last backward phase so that the L2 round trip (~1900 cycles measured) overlaps that
+  // phase's barrier; live only from there to Z (K == 1 geometries)
+  double pf[NEL][5];
 };
 
 // One task.  For the common inline case (<= 2 products) ALL operands are fetched up front — unused index fields
@@ -604,9 +628,26 @@ struct TranPhases2 {
   const SpiceyRun &R;
   WgCtx<K> &c;
   int T;
+  // Which of the beyond-resident-capacity loops of B / Z have any work (wave-uniform, fixed for the run).  On the
+  // circuits the resident geometry is sized for they are all empty, yet each one costs a bound fetch, address
+  // arithmetic and a branch: ~1200 cycles per step in Z alone before they were put behind one test.
+  uint32_t brem, zrem;
   typedef ResRegs<K, RMAX, NSV, NEL> Regs;
+  SPICEY_HD void set_remainders() {
+    brem = (P.nRestore > NSV * T ? 1u : 0u) | (P.nDynX > 0 ? 2u : 0u) | (P.n > NEL * T ? 4u : 0u) | (P.nRowX > 0 ? 8u : 0u) |
+           (P.nDynEnt > Regs::NDD * T ? 16u : 0u);
+    zrem = (P.nOut > NEL * T ? 1u : 0u) | (P.nR > NEL * T ? 2u : 0u) | (P.nC > NEL * T ? 4u : 0u) | (P.nL > 0 ? 8u : 0u) |
+           (P.nV > T ? 16u : 0u) | (P.nS > 0 ? 32u : 0u) | (P.nD > NEL * T ? 64u : 0u);
+    brem = (uint32_t)SPICEY_UNIFORM((int)brem);
+    zrem = (uint32_t)SPICEY_UNIFORM((int)zrem);
+  }
 
-  SPICEY_HD double volt16(uint32_t xi, int k) const { return xi == 0xFFFFu ? 0.0 : c.W[(size_t)xi * K + k]; }
+  // branch-free: ground (0xFFFF) reads slot 0, a valid address, and is masked afterwards, so that the reads of
+  // several elements can be issued back to back instead of one exec-masked block each
+  SPICEY_HD double volt16(uint32_t xi, int k) const {
+    const double v = c.W[(size_t)(xi == 0xFFFFu ? 0u : xi) * K + k];
+    return xi == 0xFFFFu ? 0.0 : v;
+  }
   SPICEY_HD double dv16(uint32_t ab, int k) const { return volt16(ab & 0xFFFFu, k) - volt16(ab >> 16, k); }
 
   SPICEY_HD void load_resident(int tid, const SpiceyResident &Q, Regs &rr) const {
@@ -631,17 +672,17 @@ struct TranPhases2 {
       rr.rhs[j][1] = i < P.n ? P.row_desc[(size_t)i * 2 + 1] : 0xFFFFFFFFu;  // 0xFFFFFFFF = not a resident row
       rr.eR[j] = i < P.nR ? P.R_ab[i] : 0xFFFFFFFFu;
       rr.eC[j] = i < P.nC ? P.C_ab[i] : 0xFFFFFFFFu;
-      rr.eL[j] = i < P.nL ? P.L_ab[i] : 0xFFFFFFFFu;
       rr.eD[j] = i < P.nD ? P.D_ab[i] : 0xFFFFFFFFu;
       rr.ox[j] = i < P.nOut ? (P.out_x[i] < 0 ? 0xFFFFu : (uint32_t)P.out_x[i]) : 0xFFFFu;
     }
+    if (tid < P.nV) rr.ox[0] |= (uint32_t)P.V_x[tid] << 16;  // upper half of ox[0]: W index of the branch current of source tid
   }
   // after p1_static: static entry values into registers; elements from the state entering the run
   SPICEY_HD void a0_initial(int tid, Regs &rr) const {
     const int oL = P.nC, oV = P.nC + P.nL, oD = P.nC + P.nL + P.nV;
     for (int j = 0; j < NSV; j++) {
       const int e = tid + j * T;
-      rr.dd[j] = e < P.nRestore ? P.ent_dd[e] : 0x80000000u;  // bit 31 = "not mine to stamp"
+      if (j < Regs::NDD) rr.dd[j] = e < P.nRestore ? P.ent_dd[e] : 0x80000000u;  // bit 31 = "not mine to stamp"
       for (int k = 0; k < K; k++) rr.sv[j][k] = e < P.nRestore ? R.statv[(size_t)c.inst[k] * P.nLU + e] : 0.0;
     }
     for (int k = 0; k < K; k++) {  // entries that no phase ever writes: stamped once per run
@@ -710,9 +751,10 @@ struct TranPhases2 {
 
   // ---- B: matrix = static + dynamic stamps; right-hand side -----------------------------------------
   SPICEY_HD void b_stamp(int tid, Regs &rr) const {
+    SPICEY_MARK(c, 15);
     if (tid == 0) c.flags[0] = 0;
     rr.cursor = 0;  // a new solve walks the resident slots from the start
-    for (int j = 0; j < NSV; j++) {
+    for (int j = 0; j < Regs::NDD; j++) {
       const uint32_t e = (uint32_t)(tid + j * T);
       uint32_t dd = rr.dd[j];
       SPICEY_OPAQUE(dd);
@@ -722,14 +764,32 @@ struct TranPhases2 {
         for (int k = 0; k < K; k++) c.W[(size_t)e * K + k] = rr.sv[j][k];
       }
     }
+    for (int j = Regs::NDD; j < NSV; j++) {  // plain restores (a dynamic entry this far up is left to the loop below)
+      const int e = tid + j * T;
+      if (e >= P.nDynEnt && e < P.nRestore)
+        for (int k = 0; k < K; k++) c.W[(size_t)e * K + k] = rr.sv[j][k];
+    }
+    SPICEY_MARK(c, 8);
+    if (brem & 16u)
     SPICEY_NOUNROLL
-    for (int e = tid + NSV * T; e < P.nRestore; e += T) {  // entries beyond the resident capacity
+    for (int e = tid + Regs::NDD * T; e < P.nDynEnt; e += T) {  // dynamic entries beyond the descriptor slots
       const uint32_t dd = P.ent_dd[e];
       if (dd >> 31) continue;
       double sv[K];
       for (int k = 0; k < K; k++) sv[k] = R.statv[(size_t)c.inst[k] * P.nLU + e];
       stamp_entry((uint32_t)e, dd, sv);
     }
+    if (brem & 1u)
+    SPICEY_NOUNROLL
+    for (int e = tid + NSV * T; e < P.nRestore; e += T) {  // entries beyond the resident capacity
+      if (e < P.nDynEnt) continue;  // done above
+      const uint32_t dd = P.ent_dd[e];
+      if (dd >> 31) continue;
+      double sv[K];
+      for (int k = 0; k < K; k++) sv[k] = R.statv[(size_t)c.inst[k] * P.nLU + e];
+      stamp_entry((uint32_t)e, dd, sv);
+    }
+    if (brem & 2u)
     SPICEY_NOUNROLL
     for (int t = tid; t < P.nDynX; t += T) {  // entries with > 2 dynamic stamps
       const uint32_t et = P.dynx_ent[t], e = SPICEY_IDX(et);
@@ -747,16 +807,20 @@ struct TranPhases2 {
         c.W[(size_t)e * K + k] = v;
       }
     }
+    SPICEY_MARK(c, 9);
     for (int j = 0; j < NEL; j++) {
       uint32_t d0 = rr.rhs[j][0], d1 = rr.rhs[j][1];
       SPICEY_OPAQUE(d0); SPICEY_OPAQUE(d1);
       if (d1 != 0xFFFFFFFFu) rhs_row((uint32_t)(tid + j * T), d0, d1);
     }
+    SPICEY_MARK(c, 10);
+    if (brem & 4u)
     SPICEY_NOUNROLL
     for (int r = tid + NEL * T; r < P.n; r += T) {
       const uint32_t d0 = P.row_desc[(size_t)r * 2], d1 = P.row_desc[(size_t)r * 2 + 1];
       if (d1 != 0xFFFFFFFFu) rhs_row((uint32_t)r, d0, d1);
     }
+    if (brem & 8u)
     SPICEY_NOUNROLL
     for (int t = tid; t < P.nRowX; t += T) {  // rows with > 4 contributions: +-1 gather from the CSR lists
       const uint32_t r = P.rowx[t];
@@ -791,25 +855,46 @@ struct TranPhases2 {
   }
 
   // ---- Z: record, update state, evaluate the next step's companions --------------------------------
-  SPICEY_HD void z_cap(int i, uint32_t ab, int k, size_t in, const double *g, double *oi, int cC, double &vprev, bool last) const {
-    const double dv = dv16(ab, k);
-    const double gc = g[P.nR + i];
+  SPICEY_HD void z_cap(int i, double dv, int k, size_t in, double gc, double *oi, int cC, double &vprev, bool last) const {
     if (oi) SPICEY_STREAM_STORE(&oi[cC + i], gc * (dv - vprev));
     vprev = dv;
     c.u[(size_t)i * K + k] = gc * dv;
     if (last) R.C_vprev[in * P.nC + i] = dv;
   }
-  SPICEY_HD void z_dio(int i, uint32_t ab, int k, size_t in, double *oi, int cD, int oD, bool last) const {
-    const double vd = dv16(ab, k);
-    const double *dp = R.dpar + (in * P.nD + i) * 2;
+  SPICEY_HD void z_dio(int i, double vd, int k, size_t in, double is, double dp0, double dp1, double *oi, int cD, int oD, bool last) const {
     double gg, q, irec;
-    spicey_diode_k(vd, R.D_is[in * P.nD + i], dp[0], dp[1], oi != nullptr, gg, q, irec);
+    spicey_diode_k(vd, is, dp0, dp1, oi != nullptr, gg, q, irec);
     if (oi) SPICEY_STREAM_STORE(&oi[cD + i], irec);
     c.gd[(size_t)(P.nS + i) * K + k] = gg;
     c.u[(size_t)(oD + i) * K + k] = q;
     if (last) R.D_vdprev[in * P.nD + i] = vd;
   }
-  SPICEY_HD void z_record(int tid, int64_t step, Regs &rr) const {
+  SPICEY_HD void z_prefetch(int tid, int64_t step, int k, Regs &rr) const {
+    const size_t in = (size_t)(K == 1 ? c.inst[0] : (k == 0 ? c.inst[0] : c.inst[K - 1]));
+    const double *g = R.gstat + in * P.nGstat;
+    for (int j = 0; j < NEL; j++) {
+      const int i = (SPICEY_EXP & 8) ? 0x7fffffff : tid + j * T;
+      rr.pf[j][0] = i < P.nR ? g[i] : 0.0;
+      rr.pf[j][1] = i < P.nC ? g[P.nR + i] : 0.0;
+      const bool hd = i < P.nD;
+      const double *dp = R.dpar + (in * P.nD + (hd ? i : 0)) * 2;
+      rr.pf[j][2] = hd ? R.D_is[in * P.nD + i] : 0.0;
+      rr.pf[j][3] = hd ? dp[0] : 0.0;
+      rr.pf[j][4] = hd ? dp[1] : 0.0;
+    }
+  }
+  // next step's source values: issued before the tasks of the last backward phase, parked in LDS after them
+  SPICEY_HD double z_src_fetch(int tid, int64_t step) const {
+    return (tid < P.nV && step != R.steps) ? R.src[(size_t)(step + 1) * P.nV + tid] : 0.0;
+  }
+  SPICEY_HD void z_src_park(int tid, double v) const {
+    if (tid < P.nV) c.u[(size_t)(P.nC + P.nL + P.nV + P.nD + tid) * K] = v;
+  }
+  SPICEY_HD void z_prefetch_none(Regs &rr) const {
+    for (int j = 0; j < NEL; j++)
+      for (int q = 0; q < 5; q++) rr.pf[j][q] = 0.0;
+  }
+  SPICEY_HD void z_record(int tid, int64_t step, Regs &rr, bool prefetched) const {
     const bool last = step == R.steps;
     const int oL = P.nC, oV = P.nC + P.nL, oD = P.nC + P.nL + P.nV;
     const int cR = 0, cC = P.nR, cL = P.nR + P.nC, cV = cL + P.nL, cS = cV + P.nV, cD = cS + P.nS;
@@ -823,36 +908,86 @@ struct TranPhases2 {
       double *ov = R.out_v + (in * (size_t)(R.steps + 1) + (size_t)step) * P.nOut;
       double *oi = R.out_i ? R.out_i + (in * (size_t)(R.steps + 1) + (size_t)step) * P.nCur : nullptr;
       const double *g = R.gstat + in * P.nGstat;
-      for (int j = 0; j < NEL; j++) {  // resident items: element / row / output tid + j T
+      SPICEY_MARK(c, 15);
+      // Element parameters of the resident items come from L2: all their loads are issued together (one round
+      // trip per step instead of one per element section), normally already during the last backward phase.
+      if (!(K == 1 && prefetched)) z_prefetch(tid, step, k, rr);
+      double pR[NEL], pC[NEL], pIs[NEL], pD0[NEL], pD1[NEL];
+      for (int j = 0; j < NEL; j++) { pR[j] = rr.pf[j][0]; pC[j] = rr.pf[j][1]; pIs[j] = rr.pf[j][2]; pD0[j] = rr.pf[j][3]; pD1[j] = rr.pf[j][4]; }
+      double srcn = (K == 1 && prefetched) ? 0.0 : z_src_fetch(tid, step);
+      // ... and all of them are WAITED for here, before the first result store is issued: gfx9 has one counter
+      // (vmcnt) for loads and stores, which may complete out of order, so once a store is in flight a wait for any
+      // load becomes vmcnt(0) = "until every result store has been acknowledged" (~1 us each time).
+      for (int j = 0; j < NEL; j++) { SPICEY_OPAQUE(pR[j]); SPICEY_OPAQUE(pC[j]); SPICEY_OPAQUE(pIs[j]); SPICEY_OPAQUE(pD0[j]); SPICEY_OPAQUE(pD1[j]); }
+      SPICEY_OPAQUE(srcn);
+      SPICEY_MARK(c, 0);
+      if (tid < P.nV) {  // source tid: branch current out, next step's value in (read by the next B only)
+        uint32_t vx = rr.ox[0];
+        SPICEY_OPAQUE(vx);
+        if (oi) oi[cV + tid] = c.W[(size_t)(vx >> 16) * K + k];
+        if (!last) c.u[(size_t)(oV + tid) * K + k] = (K == 1 && prefetched) ? c.u[(size_t)(oD + P.nD + tid) * K + k] : srcn;
+      }
+      SPICEY_SCHED_FENCE;
+      // resident items (element / row / output tid + j T).  All their terminal voltages are read first, back to
+      // back (one LDS round trip), then class by class so that the parameter registers die early.
+      {
+        double vo[NEL], dR[NEL];
+        for (int j = 0; j < NEL; j++) {
+          uint32_t ox = rr.ox[j], eR = rr.eR[j];
+          SPICEY_OPAQUE(ox); SPICEY_OPAQUE(eR);
+          vo[j] = volt16(ox & 0xFFFFu, k);
+          dR[j] = dv16(eR, k);
+        }
+        SPICEY_SCHED_FENCE;
+        for (int j = 0; j < NEL; j++) {
+          const int i = tid + j * T;
+          if (i < P.nOut && !(SPICEY_EXP & 16)) SPICEY_STREAM_STORE(&ov[i], vo[j]);
+          if (oi && i < P.nR && !(SPICEY_EXP & 16)) SPICEY_STREAM_STORE(&oi[cR + i], dR[j] * pR[j]);
+        }
+        SPICEY_SCHED_FENCE;
+      }
+      double dC[NEL], dD[NEL];
+      for (int j = 0; j < NEL; j++) {
+        uint32_t eC = rr.eC[j], eD = rr.eD[j];
+        SPICEY_OPAQUE(eC); SPICEY_OPAQUE(eD);
+        dC[j] = dv16(eC, k);
+        dD[j] = dv16(eD, k);
+      }
+      SPICEY_SCHED_FENCE;
+      SPICEY_MARK(c, 1);
+      for (int j = 0; j < NEL; j++) {
         const int i = tid + j * T;
-        uint32_t eR = rr.eR[j], eC = rr.eC[j], eD = rr.eD[j], ox = rr.ox[j];
-        SPICEY_OPAQUE(eR); SPICEY_OPAQUE(eC); SPICEY_OPAQUE(eD); SPICEY_OPAQUE(ox);
-        if (i < P.nOut) SPICEY_STREAM_STORE(&ov[i], volt16(ox, k));
-        SPICEY_SCHED_FENCE;
-        if (oi && i < P.nR) SPICEY_STREAM_STORE(&oi[cR + i], dv16(eR, k) * g[i]);
-        SPICEY_SCHED_FENCE;
-        if (i < P.nC) {
+        if (i < P.nC && !(SPICEY_EXP & 4)) {
           double vp = K == 1 ? rr.vprev[j][0] : (k == 0 ? rr.vprev[j][0] : rr.vprev[j][K - 1]);
-          z_cap(i, eC, k, in, g, oi, cC, vp, last);
+          z_cap(i, dC[j], k, in, pC[j], oi, cC, vp, last);
           if (K == 1 || k == 0) rr.vprev[j][0] = vp;
           else rr.vprev[j][K - 1] = vp;
         }
-        SPICEY_SCHED_FENCE;
-        if (i < P.nD) z_dio(i, eD, k, in, oi, cD, oD, last);
+      }
+      SPICEY_SCHED_FENCE;
+      SPICEY_MARK(c, 2);
+      for (int j = 0; j < NEL; j++) {
+        const int i = tid + j * T;
+        if (i < P.nD && !(SPICEY_EXP & 2)) z_dio(i, dD[j], k, in, pIs[j], pD0[j], pD1[j], oi, cD, oD, last);
         SPICEY_SCHED_FENCE;
       }
+      SPICEY_MARK(c, 3);
+      if ((SPICEY_EXP & 32) || !zrem) continue;
+      if (zrem & 1u)
       SPICEY_NOUNROLL
       for (int i = tid + NEL * T; i < P.nOut; i += T) ov[i] = P.out_x[i] < 0 ? 0.0 : c.W[(size_t)P.out_x[i] * K + k];
-      if (oi) {
+      if (oi && (zrem & 2u)) {
         SPICEY_NOUNROLL
         for (int i = tid + NEL * T; i < P.nR; i += T) oi[cR + i] = dv16(P.R_ab[i], k) * g[i];
       }
+      if (zrem & 4u)
       SPICEY_NOUNROLL
       for (int i = tid + NEL * T; i < P.nC; i += T) {  // beyond the resident capacity: vPrev lives in the state array
         double vp = R.C_vprev[in * P.nC + i];
-        z_cap(i, P.C_ab[i], k, in, g, oi, cC, vp, false);
+        z_cap(i, dv16(P.C_ab[i], k), k, in, g[P.nR + i], oi, cC, vp, false);
         R.C_vprev[in * P.nC + i] = vp;
       }
+      if (zrem & 8u)
       SPICEY_NOUNROLL
       for (int i = tid; i < P.nL; i += T) {
         const double dv = dv16(P.L_ab[i], k);
@@ -861,11 +996,13 @@ struct TranPhases2 {
         c.u[(size_t)(oL + i) * K + k] = il;
         if (last) R.L_iprev[in * P.nL + i] = il;
       }
+      if (zrem & 16u)
       SPICEY_NOUNROLL
-      for (int i = tid; i < P.nV; i += T) {
+      for (int i = tid + T; i < P.nV; i += T) {
         if (oi) oi[cV + i] = c.W[(size_t)P.V_x[i] * K + k];
         if (!last) c.u[(size_t)(oV + i) * K + k] = R.src[(size_t)(step + 1) * P.nV + i];
       }
+      if (zrem & 32u)
       SPICEY_NOUNROLL
       for (int i = tid; i < P.nS; i += T) {
         const int on = c.ison[(size_t)i * K + k];
@@ -875,8 +1012,12 @@ struct TranPhases2 {
         c.gd[(size_t)i * K + k] = gs;
         if (last) R.S_ison[in * P.nS + i] = on;
       }
+      if (zrem & 64u)
       SPICEY_NOUNROLL
-      for (int i = tid + NEL * T; i < P.nD; i += T) z_dio(i, P.D_ab[i], k, in, oi, cD, oD, last);
+      for (int i = tid + NEL * T; i < P.nD; i += T) {
+        const double *dp = R.dpar + (in * P.nD + i) * 2;
+        z_dio(i, dv16(P.D_ab[i], k), k, in, R.D_is[in * P.nD + i], dp[0], dp[1], oi, cD, oD, last);
+      }
       SPICEY_SCHED_FENCE;
     }
   }
@@ -886,7 +1027,8 @@ template <int K, int RMAX, int NSV, int NEL, class Exec>
 SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, WgCtx<K> &c, int wg) {
   const int T = ex.threads();
   TranPhases<K> ph{P, R, c, T};
-  TranPhases2<K, RMAX, NSV, NEL> p2{P, R, c, T};
+  TranPhases2<K, RMAX, NSV, NEL> p2{P, R, c, T, 0u, 0u};
+  p2.set_remainders();
   typedef ResRegs<K, RMAX, NSV, NEL> Regs;
   ex.phase(SPICEY_PH_PRO, [&](int tid) {
     if (tid == 0) { c.flags[0] = 0; c.flags[1] = 0; c.flags[2] = -1; }
@@ -915,10 +1057,19 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
   }
   const int u_end = Q.tail_n > 0 ? Q.tail_first : nL;
   const int k_begin = Q.tail_n > 0 ? Q.tail_first + Q.tail_n : nL;
+  const bool z_pre = K == 1 && k_begin < 2 * nL;  // Z's parameter fetch rides on the last backward phase
   for (int64_t step = 0; step <= R.steps && code == 0; step++) {
     int iter = 0;
     for (;;) {
-      ex.phase(SPICEY_PH_B, [&](int tid) { p2.b_stamp(tid, ex.template regs<Regs>(tid)); });
+      ex.phase(SPICEY_PH_B, [&](int tid) {
+        // the next step's source values ride on B (a long phase with few live registers): fetched first, parked in
+        // LDS last; Z moves them into place
+        double sn = K == 1 ? p2.z_src_fetch(tid, step) : 0.0;
+        SPICEY_SCHED_FENCE;
+        p2.b_stamp(tid, ex.template regs<Regs>(tid));
+        SPICEY_SCHED_FENCE;
+        if (K == 1) p2.z_src_park(tid, sn);
+      });
       for (int d = 0; d < R.debug_empty_phases; d++) ex.phase(SPICEY_PH_S, [&](int) {});  // diagnostics: cost of a bare phase
       // factor levels [0, u_end) | tail [u_end, k_begin) by one wave | backward levels [k_begin, 2 nL)
       for (int p = 0; p < u_end; p++) {
@@ -934,11 +1085,23 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
           else spicey_exec_rec16<K, true>(c, P.ovf16, r[0], r[1], r[2], r[3]);
         });
       }
-      for (int p = k_begin; p < 2 * nL; p++) {
+      for (int p = k_begin; p < 2 * nL - 1; p++) {
         const int l = 2 * nL - 1 - p;
         ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) {
           spicey_uk_phase<K, RMAX, NSV, NEL, true>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
         });
+      }
+      // the last backward phase (level 0) is peeled: it also issues Z's parameter fetch.  (Every path through the
+      // iteration defines the prefetch registers, so they are not live around the time loop.)
+      if (k_begin < 2 * nL) {
+        const int p = 2 * nL - 1;
+        ex.phase(SPICEY_PH_K0, [&](int tid) {
+          spicey_uk_phase<K, RMAX, NSV, NEL, true>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
+          SPICEY_SCHED_FENCE;  // after the tasks, not among them: their registers are free by now
+          if (K == 1) p2.z_prefetch(tid, step, 0, ex.template regs<Regs>(tid));
+        });
+      } else if (K == 1) {
+        p2.z_prefetch_none(ex.template regs<Regs>(0));
       }
       if (c.flags[1]) { code = 1; err_step = step; err_iter = iter; break; }
       if (P.nS == 0) break;
@@ -958,7 +1121,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
       if (tid == 0 && R.iters)
         for (int k = 0; k < K; k++)
           if (c.valid[k]) R.iters[(size_t)c.inst[k] * (size_t)(R.steps + 1) + (size_t)step] = iter + 1;
-      p2.z_record(tid, step, ex.template regs<Regs>(tid));
+      p2.z_record(tid, step, ex.template regs<Regs>(tid), z_pre);
     });
   }
   ex.phase(SPICEY_PH_PRO, [&](int tid) {

@@ -15,7 +15,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspicey_hip.so")
+LIB_PATH = os.environ.get("SPICEY_HIP_LIB") or os.path.join(_HERE, "libspicey_hip.so")  # same override as ts/spiceyHip.ts
 _LIB = None
 
 EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "spicey_get_state", "spicey_last_solve_count",
