@@ -27,7 +27,8 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "_ref", "liboracle.so")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "spicey_ref.c")):
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                                                     for f in ("spicey_ref.c", "spicey_ref_ac.c")):
             build()
         L = C.CDLL(path)
         f64p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
@@ -36,6 +37,8 @@ def lib():
                                      f64p, f64p, f64p, i32p, C.POINTER(C.c_int64), i32p]
         L.spicey_ref_timestep.restype = None
         L.spicey_ref_timestep.argtypes = [C.c_double, C.c_double, f64p, C.POINTER(C.c_int64)]
+        L.spicey_ref_ac.restype = C.c_int32
+        L.spicey_ref_ac.argtypes = [C.POINTER(abi.SpiceyDesc), C.c_int32, C.c_int64, f64p, f64p, f64p, f64p, i32p]
         _LIB = L
     return _LIB
 
@@ -71,6 +74,28 @@ class OracleBackend:
             if rc != abi.OK and status == abi.OK:
                 status, detail = rc, f"singular at inst {k} step {es.value} iter {ei.value}"
         return {"status": status, "detail": detail, "out_v": out_v, "out_i": out_i, "iters": iters, "state": st}
+
+
+    def run_ac(self, flat: abi.FlatCircuit, freqs: np.ndarray, vph: np.ndarray, want_currents: bool = True) -> dict:
+        """AC sweep (oracle/spicey_ref_ac.c).  vph: complex [nV]; out_v complex [n_inst][n_freq][n_nodes],
+        out_i complex [n_inst][n_freq][nR+nC+nL+nV].  status 1 singular, 5 complex divide by ~0, 6 resistor <= 0."""
+        L = lib()
+        d = flat.desc()
+        ni, nf = flat.n_inst, len(freqs)
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        vph = np.ascontiguousarray(vph, dtype=np.complex128).reshape(flat.nV)
+        ncur = flat.nR + flat.nC + flat.nL + flat.nV
+        out_v = np.zeros((ni, nf, flat.n_nodes), np.complex128)
+        out_i = np.zeros((ni, nf, ncur), np.complex128) if want_currents else None
+        status, detail = abi.OK, ""
+        ei = C.c_int32(-1)
+        for k in range(ni):
+            rc = L.spicey_ref_ac(C.byref(d), k, nf, _p(freqs, C.c_double), _p(vph.view(np.float64), C.c_double),
+                                 _p(out_v[k].view(np.float64), C.c_double),
+                                 _p(out_i[k].view(np.float64), C.c_double) if want_currents else None, C.byref(ei))
+            if rc != abi.OK and status == abi.OK:
+                status, detail = rc, {1: "Singular matrix (complex)", 5: "Complex divide by ~0", 6: f"resistor {ei.value} <= 0"}.get(rc, str(rc))
+        return {"status": status, "detail": detail, "out_v": out_v, "out_i": out_i}
 
 
 def timestep(dt_requested: float, tstop: float):

@@ -97,10 +97,13 @@ def simulateTRAN(ckt: ParsedCircuit, backend=None, as_lists: bool = True) -> Opt
 
 
 def simulate(netlist_text: str, backend=None) -> dict:
-    """simulate.ts:5-10.  `ac` is out of scope for this build and always None."""
+    """simulate.ts:5-10: parse, AC sweep (if an .ac card is present), transient (if a .tran card is present)."""
+    from .ac import simulateAC  # (ac.py imports this module's number formatter)
+
     circuit = parseNetlist(netlist_text)
+    ac = simulateAC(circuit, backend=backend)
     tran = simulateTRAN(circuit, backend=backend)
-    return {"circuit": circuit, "ac": None, "tran": tran}
+    return {"circuit": circuit, "ac": ac, "tran": tran}
 
 
 def formatTranResult(tran: Optional[dict]) -> str:

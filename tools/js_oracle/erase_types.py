@@ -35,6 +35,16 @@ FILES = [
     "analysis/simulateTRAN.ts",
     "formatting/formatTranResult.ts",
 ]
+# AC sweep path, erased with `--ac`
+AC_FILES = [
+    "math/Complex.ts",
+    "math/solveComplex.ts",
+    "stamping/stampAdmittanceComplex.ts",
+    "stamping/stampVoltageSourceComplex.ts",
+    "utils/logspace.ts",
+    "analysis/simulateAC.ts",
+    "formatting/formatAcResult.ts",
+]
 
 
 def strip_type_blocks(src: str) -> str:
@@ -98,6 +108,14 @@ def erase(src: str, rel: str) -> str:
         s = re.sub(r"function formatTranResult\(\s*tran: \{[\s\S]*?\} \| null,\s*\)",
                    "function formatTranResult(tran)", s)
 
+    if rel.endswith("formatAcResult.ts"):
+        s = re.sub(r"function formatAcResult\(\s*ac: \{[\s\S]*?\} \| null,\s*\)", "function formatAcResult(ac)", s)
+    if rel.endswith("simulateAC.ts"):  # object-typed return annotation
+        s = re.sub(r"\): \{ A: Complex\[\]\[\]; b: Complex\[\] \} \{", ") {", s)
+    if rel.endswith("Complex.ts"):  # class field declarations and typed method parameters
+        s = re.sub(r"^  (re|im): number\n", "", s, flags=re.M)
+        s = re.sub(r"^(  (?:static )?\w+)\(([^)]*)\) \{", lambda m: f"{m.group(1)}({erase_param_types(m.group(2))}) {{", s, flags=re.M)
+
     # function declarations: parameter lists and return annotations
     def fn_repl(m):
         return f"{m.group(1)}({erase_param_types(m.group(2))}) {{"
@@ -131,8 +149,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("outdir")
     ap.add_argument("--diff", action="store_true", help="print source→erased diffs for review")
+    ap.add_argument("--ac", action="store_true", help="also erase the AC sweep path")
     args = ap.parse_args()
-    for rel in FILES:
+    for rel in FILES + (AC_FILES if args.ac else []):
         with open(os.path.join(REF, rel)) as f:
             src = f.read()
         out = erase(src, rel)
