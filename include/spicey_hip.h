@@ -44,6 +44,7 @@ extern "C" {
 #define SPICEY_ERR_BAD_DESC 2
 #define SPICEY_ERR_HIP 3
 #define SPICEY_ERR_NO_DEVICE 4 /* the product path has no CPU fallback: no GPU -> this error */
+#define SPICEY_ERR_COMPLEX_DIV 5 /* AC only: host maps to Error("Complex divide by ~0"), math/Complex.ts:40-42 */
 
 /* Flat circuit descriptor: the ParsedCircuit of parseNetlist.ts:85-105 as SoA arrays.
  * All pointers are HOST pointers, read during spicey_create only. */
@@ -162,6 +163,29 @@ int32_t spicey_debug_phase_cycles(SpiceyHandle *h, uint64_t *out, int32_t n);
 
 /* Library build info: "spicey_hip <abi> gfx950 …" */
 const char *spicey_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * AC sweep: replaces the per-frequency body of
+ *   simulateAC(ckt)              /root/reference/lib/analysis/simulateAC.ts:64-130
+ * i.e. buildLinearSystemForAC (:25-62, lib/stamping/stamp{Admittance,VoltageSource}Complex.ts), solveComplex
+ * (lib/math/solveComplex.ts:4-73) and the recording (:84-126), for every (instance, frequency) pair in one launch.
+ * The host keeps the frequency list (buildFrequencyArray :9-23, utils/logspace.ts — Math.pow is engine-defined), the
+ * source phasors (Complex.fromPolar, math/Complex.ts:16-19) and the `R <name> must be > 0` check (:39).
+ * Diodes and switches of the descriptor are ignored, like the reference's AC analysis ignores them.
+ *   freqs   [n_freq] Hz
+ *   vph     [n_inst][nV][2] source phasors (re, im)
+ *   out_v   [n_inst][n_freq][n_out][2]   complex node voltages (re, im)
+ *   out_i   [n_inst][n_freq][nR+nC+nL+nV][2] complex currents in the reference's recording order R, C, L, V, or NULL
+ * HOST buffers; blocking.  Status: SPICEY_ERR_SINGULAR -> Error("Singular matrix (complex)") (solveComplex.ts:28),
+ * SPICEY_ERR_COMPLEX_DIV -> Error("Complex divide by ~0") (a pivot with |z|^2 < 1e-15, Complex.ts:40-42); the message of
+ * spicey_ac_last_error names the first failing (instance, frequency), the one at which the reference would throw. */
+typedef struct SpiceyAcHandle SpiceyAcHandle;
+int32_t spicey_ac_create(const SpiceyDesc *desc, const SpiceyOptions *opt /* device, threads, force_global */, SpiceyAcHandle **out);
+int32_t spicey_ac_run(SpiceyAcHandle *h, int64_t n_freq, const double *freqs, const double *vph, double *out_v, double *out_i);
+int32_t spicey_ac_get_info(SpiceyAcHandle *h, SpiceyInfo *info);
+double spicey_ac_last_kernel_ms(SpiceyAcHandle *h);
+const char *spicey_ac_last_error(SpiceyAcHandle *h);
+void spicey_ac_destroy(SpiceyAcHandle *h);
 
 #ifdef __cplusplus
 }

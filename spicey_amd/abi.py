@@ -14,7 +14,7 @@ import numpy as np
 from .netlist import EPS, ParsedCircuit
 
 ABI_VERSION = 1
-OK, ERR_SINGULAR, ERR_BAD_DESC, ERR_HIP, ERR_NO_DEVICE = 0, 1, 2, 3, 4
+OK, ERR_SINGULAR, ERR_BAD_DESC, ERR_HIP, ERR_NO_DEVICE, ERR_COMPLEX_DIV = 0, 1, 2, 3, 4, 5
 
 _I32P = C.POINTER(C.c_int32)
 _F64P = C.POINTER(C.c_double)

@@ -21,7 +21,7 @@ from . import abi
 from .netlist import EPS, ParsedCircuit, js_object_key_order
 from .simulate import _to_precision6_array
 
-ERR_COMPLEX_DIV = 5  # "Complex divide by ~0" (Complex.ts:42,50)
+ERR_COMPLEX_DIV = abi.ERR_COMPLEX_DIV  # "Complex divide by ~0" (Complex.ts:42,50)
 
 
 def logspace(f1: float, f2: float, pointsPerDecade: float) -> List[float]:

@@ -1,0 +1,224 @@
+// ac.hip — AC sweep on the GPU: kernel and C-ABI (spicey_ac_* of include/spicey_hip.h).
+//
+// One workgroup per (instance, frequency) pair runs a whole complex MNA solve (ac_exec.h): the pairs are
+// independent (simulateAC.ts:80 `for (const f of freqs)`), so the sweep is one launch of n_inst * n_freq workgroups.
+// Workspace: nW complex entries = 16 bytes each, in LDS when it fits (<= ~10 000 entries), else one slice of a global
+// buffer per workgroup.  The schedule ("program") is the transient one of symbolic.cpp built from the descriptor
+// without diodes and switches.  No CPU path: without a HIP device spicey_ac_create returns SPICEY_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spicey_hip.h"
+#include "ac_exec.h"
+#include "kernels.h"
+#include "symbolic.h"
+
+namespace {
+
+struct GpuAcExec {
+  __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
+  template <class F>
+  __device__ __forceinline__ void phase(int, F f) {
+    f((int)threadIdx.x);
+    __syncthreads();
+  }
+};
+
+template <bool LDS>
+__global__ void __launch_bounds__(1024) spicey_ac_kernel(SpiceyProg P, SpiceyAcRun R) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int32_t flags[2];
+  const int64_t slot = (int64_t)blockIdx.x;
+  SpiceyCx *W = LDS ? (SpiceyCx *)smem : (SpiceyCx *)R.gW + (size_t)slot * (size_t)P.nW;
+  GpuAcExec ex;
+  spicey_ac_solve(ex, P, R, W, flags, slot);
+}
+
+}  // namespace
+
+struct SpiceyAcHandle {
+  HostProgram hp;
+  SpiceyProg dprog{};
+  SpiceyOptions opt{};
+  int n_inst = 0, T = 256, device = 0;
+  bool lds = true;
+  size_t lds_bytes = 0;
+  void *d_blob = nullptr;
+  double *d_R = nullptr, *d_C = nullptr, *d_L = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_ms = 0.0;
+  std::string err;
+};
+
+static std::string g_ac_err;
+
+extern "C" const char *spicey_ac_last_error(SpiceyAcHandle *h) { return h ? h->err.c_str() : g_ac_err.c_str(); }
+
+extern "C" void spicey_ac_destroy(SpiceyAcHandle *h) {
+  if (!h) return;
+  void *ptrs[] = {h->d_blob, h->d_R, h->d_C, h->d_L};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+#define ACCHK(h, call)                                                 \
+  do {                                                                 \
+    hipError_t e__ = (call);                                           \
+    if (e__ != hipSuccess) {                                           \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);   \
+      return SPICEY_ERR_HIP;                                           \
+    }                                                                  \
+  } while (0)
+
+static int32_t ac_upload(SpiceyAcHandle *h, double **dst, const double *src, size_t count) {
+  *dst = nullptr;
+  ACCHK(h, hipMalloc((void **)dst, (count ? count : 1) * sizeof(double)));
+  if (count && src) ACCHK(h, hipMemcpy(*dst, src, count * sizeof(double), hipMemcpyHostToDevice));
+  return SPICEY_OK;
+}
+
+extern "C" int32_t spicey_ac_create(const SpiceyDesc *desc, const SpiceyOptions *opt, SpiceyAcHandle **out) {
+  if (!out) { g_ac_err = "null out pointer"; return SPICEY_ERR_BAD_DESC; }
+  *out = nullptr;
+  if (!desc) { g_ac_err = "null descriptor"; return SPICEY_ERR_BAD_DESC; }
+  SpiceyAcHandle *h = new SpiceyAcHandle();
+  if (opt) h->opt = *opt;
+  SpiceyDesc d = *desc;  // simulateAC.ts:38-59 stamps R, C, L and V only
+  d.nS = 0;
+  d.nD = 0;
+  std::string err;
+  int32_t rc = spicey_build_program(&d, h->hp, err);
+  if (rc != SPICEY_OK) {
+    g_ac_err = err;
+    delete h;
+    return rc;
+  }
+  h->n_inst = desc->n_inst;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_ac_err = "no HIP device: libspicey_hip has no CPU path";
+    delete h;
+    return SPICEY_ERR_NO_DEVICE;
+  }
+  h->device = h->opt.device;
+  auto fail = [&](int32_t code) {
+    g_ac_err = h->err;
+    spicey_ac_destroy(h);
+    return code;
+  };
+  if (h->device < 0 || h->device >= ndev) { h->err = "device ordinal out of range"; return fail(SPICEY_ERR_BAD_DESC); }
+  if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return fail(SPICEY_ERR_HIP); }
+  const SpiceyProg &P = h->hp.hdr;
+  h->lds_bytes = (size_t)P.nW * sizeof(SpiceyCx);
+  h->lds = !h->opt.force_global && h->lds_bytes + 64 <= SPICEY_LDS_MAX;
+  const int n = P.n;
+  h->T = h->opt.threads > 0 ? h->opt.threads : (n <= 48 ? 64 : n <= 160 ? 128 : n <= 1200 ? 256 : n <= 4000 ? 512 : 1024);
+  if (h->T > 1024 || (h->T & 63) || h->T < 64) { h->err = "threads must be a multiple of 64 in [64, 1024]"; return fail(SPICEY_ERR_BAD_DESC); }
+  if (hipMalloc(&h->d_blob, h->hp.blob.size()) != hipSuccess ||
+      hipMemcpy(h->d_blob, h->hp.blob.data(), h->hp.blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    h->err = "upload of the program failed";
+    return fail(SPICEY_ERR_HIP);
+  }
+  h->dprog = h->hp.bind(h->d_blob);
+  const size_t ni = (size_t)h->n_inst;
+  if ((rc = ac_upload(h, &h->d_R, desc->R_val, ni * P.nR)) != SPICEY_OK) return fail(rc);
+  if ((rc = ac_upload(h, &h->d_C, desc->C_val, ni * P.nC)) != SPICEY_OK) return fail(rc);
+  if ((rc = ac_upload(h, &h->d_L, desc->L_val, ni * P.nL)) != SPICEY_OK) return fail(rc);
+  if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    h->err = "stream/event creation failed";
+    return fail(SPICEY_ERR_HIP);
+  }
+  *out = h;
+  return SPICEY_OK;
+}
+
+extern "C" int32_t spicey_ac_get_info(SpiceyAcHandle *h, SpiceyInfo *info) {
+  if (!h || !info) return SPICEY_ERR_BAD_DESC;
+  memset(info, 0, sizeof(*info));
+  info->n_var = h->hp.hdr.n;
+  info->nnz_a = h->hp.nnzA;
+  info->nnz_lu = h->hp.hdr.nLU;
+  info->n_levels = h->hp.hdr.nLevels;
+  info->threads = h->T;
+  info->inst_per_wg = 1;
+  info->lds_bytes = h->lds ? (int32_t)h->lds_bytes : 0;
+  info->n_cur = h->hp.hdr.nR + h->hp.hdr.nC + h->hp.hdr.nL + h->hp.hdr.nV;
+  info->n_out = h->hp.hdr.nOut;
+  info->interpreter = 1;
+  info->wgs_per_inst = 1;
+  info->program_bytes = (int64_t)h->hp.blob.size();
+  return SPICEY_OK;
+}
+
+extern "C" double spicey_ac_last_kernel_ms(SpiceyAcHandle *h) { return h ? h->last_ms : 0.0; }
+
+extern "C" int32_t spicey_ac_run(SpiceyAcHandle *h, int64_t n_freq, const double *freqs, const double *vph, double *out_v, double *out_i) {
+  if (!h) return SPICEY_ERR_BAD_DESC;
+  const SpiceyProg &P = h->hp.hdr;
+  if (n_freq < 0 || (n_freq > 0 && (!freqs || !out_v)) || (P.nV > 0 && !vph)) { h->err = "bad run arguments"; return SPICEY_ERR_BAD_DESC; }
+  if (n_freq == 0) return SPICEY_OK;
+  if (h->hp.structurally_singular) { h->err = "Singular matrix (complex): structurally singular"; return SPICEY_ERR_SINGULAR; }
+  const size_t slots = (size_t)h->n_inst * (size_t)n_freq;
+  if (slots > 0x7fffffffull) { h->err = "n_inst * n_freq exceeds the grid limit"; return SPICEY_ERR_BAD_DESC; }
+  ACCHK(h, hipSetDevice(h->device));
+  const int nCur = P.nR + P.nC + P.nL + P.nV;
+  double *d_f = nullptr, *d_ph = nullptr, *d_ov = nullptr, *d_oi = nullptr, *d_gW = nullptr;
+  int32_t *d_status = nullptr;
+  std::vector<int32_t> status(slots);
+  int32_t rc = SPICEY_OK;
+  auto body = [&]() -> int32_t {
+    ACCHK(h, hipMalloc((void **)&d_f, (size_t)n_freq * sizeof(double)));
+    ACCHK(h, hipMalloc((void **)&d_ph, std::max<size_t>(1, (size_t)h->n_inst * P.nV * 2) * sizeof(double)));
+    ACCHK(h, hipMalloc((void **)&d_ov, std::max<size_t>(1, slots * (size_t)P.nOut * 2) * sizeof(double)));
+    if (out_i) ACCHK(h, hipMalloc((void **)&d_oi, std::max<size_t>(1, slots * (size_t)nCur * 2) * sizeof(double)));
+    ACCHK(h, hipMalloc((void **)&d_status, slots * sizeof(int32_t)));
+    if (!h->lds) ACCHK(h, hipMalloc((void **)&d_gW, slots * (size_t)P.nW * sizeof(SpiceyCx)));
+    ACCHK(h, hipMemcpyAsync(d_f, freqs, (size_t)n_freq * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (P.nV > 0) ACCHK(h, hipMemcpyAsync(d_ph, vph, (size_t)h->n_inst * P.nV * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    SpiceyAcRun R{};
+    R.R_val = h->d_R; R.C_val = h->d_C; R.L_val = h->d_L;
+    R.freqs = d_f; R.vph = d_ph; R.out_v = d_ov; R.out_i = d_oi; R.gW = d_gW; R.status = d_status;
+    R.n_freq = n_freq; R.n_inst = h->n_inst;
+    ACCHK(h, hipEventRecord(h->ev0, h->stream));
+    if (h->lds) {
+      auto kern = spicey_ac_kernel<true>;
+      if (h->lds_bytes > 48 * 1024)
+        ACCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+      hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(h->T), h->lds_bytes, h->stream, h->dprog, R);
+    } else {
+      hipLaunchKernelGGL(spicey_ac_kernel<false>, dim3((unsigned)slots), dim3(h->T), 0, h->stream, h->dprog, R);
+    }
+    ACCHK(h, hipGetLastError());
+    ACCHK(h, hipEventRecord(h->ev1, h->stream));
+    ACCHK(h, hipMemcpyAsync(status.data(), d_status, slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    ACCHK(h, hipMemcpyAsync(out_v, d_ov, slots * (size_t)P.nOut * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (out_i) ACCHK(h, hipMemcpyAsync(out_i, d_oi, slots * (size_t)nCur * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    ACCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_ms = ms;
+    return SPICEY_OK;
+  };
+  rc = body();
+  void *tmp[] = {d_f, d_ph, d_ov, d_oi, d_status, d_gW};
+  for (void *p : tmp)
+    if (p) (void)hipFree(p);
+  if (rc != SPICEY_OK) return rc;
+  // the reference stops at the first frequency that throws (simulateAC.ts:80-83): report the first failing slot
+  for (size_t s = 0; s < slots; s++)
+    if (status[s] != 0) {
+      const bool sing = status[s] == 1;
+      h->err = std::string(sing ? "Singular matrix (complex)" : "Complex divide by ~0") + " at inst " + std::to_string(s / (size_t)n_freq) +
+               " frequency index " + std::to_string(s % (size_t)n_freq);
+      return sing ? SPICEY_ERR_SINGULAR : SPICEY_ERR_COMPLEX_DIV;
+    }
+  return SPICEY_OK;
+}

@@ -1,0 +1,198 @@
+// ac_exec.h — AC sweep: one complex MNA solve per (instance, frequency).
+//
+// Replaces the per-frequency body of simulateAC (/root/reference/lib/analysis/simulateAC.ts:80-126):
+//   buildLinearSystemForAC (:25-62)  -> S: entries gathered from the static stamp lists with complex admittances
+//   solveComplex (lib/math/solveComplex.ts:4-73) -> U_l / K_l: the same level-scheduled sparse LU as the transient
+//                                       kernel (symbolic.cpp), in complex arithmetic, fixed pivot order
+//   recording (:84-126)              -> Z: node voltages, currents of R, C, L, V
+// Every (instance, frequency) pair is independent: one workgroup each, workspace in LDS (16 bytes per entry) or,
+// for large circuits, in global memory.  The phase code is shared with the test suite's CPU emulator (same
+// SPICEY_HD / Exec.phase() arrangement as tran_exec.h); diodes and switches do not take part (the reference's AC
+// analysis ignores them), so the program is built from the descriptor with nS = nD = 0.
+#pragma once
+#include "tran_exec.h"
+
+#define SPICEY_ERR_COMPLEX_DIV_CODE 5
+
+struct SpiceyAcRun {
+  const double *R_val, *C_val, *L_val;  // [n_inst][n<kind>]
+  const double *freqs;                  // [n_freq]
+  const double *vph;                    // [n_inst][nV][2] source phasors
+  double *out_v;                        // [n_inst][n_freq][nOut][2]
+  double *out_i;                        // [n_inst][n_freq][nR+nC+nL+nV][2] or null
+  double *gW;                           // [n_workgroups][nW][2] global workspace, or null when the workspace is in LDS
+  int32_t *status;                      // [n_inst * n_freq] 0 ok, 1 singular, 5 complex divide by ~0
+  int64_t n_freq;
+  int32_t n_inst;
+};
+
+struct SpiceyCx { double re, im; };
+
+SPICEY_HD SpiceyCx cx_mul(SpiceyCx a, SpiceyCx b) { return SpiceyCx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+SPICEY_HD SpiceyCx cx_sub(SpiceyCx a, SpiceyCx b) { return SpiceyCx{a.re - b.re, a.im - b.im}; }
+SPICEY_HD SpiceyCx cx_add(SpiceyCx a, SpiceyCx b) { return SpiceyCx{a.re + b.re, a.im + b.im}; }
+
+template <class Exec>
+struct AcPhases {
+  const SpiceyProg &P;
+  const SpiceyAcRun &R;
+  SpiceyCx *W;      // [nW]
+  int32_t *flags;   // [0] error code of this solve
+  int T;
+  size_t inst;
+  double w;         // 2 pi f   (simulateAC.ts:33,43: twoPi * f * C = (twoPi * f) * C)
+
+  // 1/z for pivots, with the reference's guards: |z| < EPS -> "Singular matrix (complex)" (solveComplex.ts:28),
+  // |z|^2 < EPS -> "Complex divide by ~0" (Complex.ts:40-42, reached through entry.div(pivot))
+  SPICEY_HD SpiceyCx pivot_inv(SpiceyCx z) const {
+    const double d = z.re * z.re + z.im * z.im;
+    if (d < SPICEY_EPS) {
+      const int code = d < SPICEY_EPS * SPICEY_EPS ? 1 : SPICEY_ERR_COMPLEX_DIV_CODE;
+      if (flags[0] == 0 || code == 1) flags[0] = code;  // benign race: any writer leaves a non-zero code
+      return SpiceyCx{0.0, 0.0};
+    }
+    return SpiceyCx{z.re / d, -z.im / d};
+  }
+  // admittance of static-stamp slot idx: [1/R | j w C | 1/(j w L) | 1] (simulateAC.ts:38-55)
+  SPICEY_HD SpiceyCx admittance(uint32_t idx) const {
+    if (idx < (uint32_t)P.nR) return SpiceyCx{1.0 / R.R_val[inst * P.nR + idx], 0.0};
+    idx -= P.nR;
+    if (idx < (uint32_t)P.nC) return SpiceyCx{0.0, w * R.C_val[inst * P.nC + idx]};
+    idx -= P.nC;
+    if (idx < (uint32_t)P.nL) {
+      const double wl = w * R.L_val[inst * P.nL + idx];
+      if (fabs(wl) < SPICEY_EPS) return SpiceyCx{0.0, 0.0};
+      const double d = wl * wl;
+      if (d < SPICEY_EPS) { flags[0] = SPICEY_ERR_COMPLEX_DIV_CODE; return SpiceyCx{0.0, 0.0}; }
+      return SpiceyCx{0.0 / d, (0.0 - wl) / d};  // Complex.from(1,0).div(Complex.from(0, wl))
+    }
+    return SpiceyCx{1.0, 0.0};
+  }
+  SPICEY_HD SpiceyCx volt(int32_t xi) const { return xi < 0 ? SpiceyCx{0.0, 0.0} : W[xi]; }
+
+  SPICEY_HD void s_stamp(int tid) const {
+    SPICEY_NOUNROLL
+    for (int e = tid; e < P.nLU; e += T) {
+      SpiceyCx v{0.0, 0.0};
+      for (uint32_t j = P.stat_ptr[e]; j < P.stat_ptr[e + 1]; j++) {
+        const uint32_t ix = P.stat_idx[j];
+        const SpiceyCx g = admittance(SPICEY_IDX(ix));
+        v = (ix & SPICEY_NEG) ? cx_sub(v, g) : cx_add(v, g);
+      }
+      if (P.ent_flag[e] & 1) v = pivot_inv(v);  // leaf diagonal: final as stamped
+      W[e] = v;
+    }
+    const uint32_t oV = (uint32_t)(P.nC + P.nL);
+    SPICEY_NOUNROLL
+    for (int r = tid; r < P.n; r += T) {  // b[j] += Vph of source rows (stampVoltageSourceComplex.ts:34)
+      SpiceyCx acc{0.0, 0.0};
+      for (uint32_t j = P.rhs_ptr[r]; j < P.rhs_ptr[r + 1]; j++) {
+        const uint32_t ix = P.rhs_idx[j], u = SPICEY_IDX(ix);
+        if (u < oV || u >= oV + (uint32_t)P.nV) continue;  // capacitor / inductor companions are transient-only
+        const double *ph = R.vph + (inst * P.nV + (u - oV)) * 2;
+        const SpiceyCx v{ph[0], ph[1]};
+        acc = (ix & SPICEY_NEG) ? cx_sub(acc, v) : cx_add(acc, v);
+      }
+      W[P.nLU + r] = acc;
+    }
+  }
+  SPICEY_HD void u_level(int tid, int l) const {
+    const int nw = T >> 6, wv = tid >> 6, lane = tid & 63;
+    for (uint32_t s = P.lvl_slice[l] + wv; s < P.lvl_slice[l + 1]; s += nw) {
+      const uint32_t t = s * 64 + lane;
+      const uint32_t tgt = P.upd_tgt[t];
+      if (tgt == SPICEY_TGT_PAD) continue;
+      const uint32_t cnt = P.upd_cnt[t];
+      const uint32_t off = P.upd_slice[s].off + lane;
+      const uint32_t ti = SPICEY_IDX(tgt);
+      SpiceyCx acc = W[ti];
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t li = P.upd_pairs[off + (j * 3 + 0) * 64];
+        const uint32_t di = P.upd_pairs[off + (j * 3 + 1) * 64];
+        const uint32_t ui = P.upd_pairs[off + (j * 3 + 2) * 64];
+        acc = cx_sub(acc, cx_mul(cx_mul(W[li], W[di]), W[ui]));
+      }
+      if (tgt & SPICEY_TGT_RECIP) acc = pivot_inv(acc);
+      W[ti] = acc;
+    }
+  }
+  SPICEY_HD void k_level(int tid, int l) const {
+    const int nw = T >> 6, wv = tid >> 6, lane = tid & 63;
+    for (uint32_t s = P.bk_lvl_slice[l] + wv; s < P.bk_lvl_slice[l + 1]; s += nw) {
+      const uint32_t t = s * 64 + lane;
+      const uint32_t yi = P.bk_x[t];
+      if (yi == SPICEY_TGT_PAD) continue;
+      const uint32_t cnt = P.bk_cnt[t];
+      const uint32_t off = P.bk_slice[s].off + lane;
+      SpiceyCx acc = W[yi];
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t ki = P.bk_pairs[off + (j * 3 + 0) * 64];
+        const uint32_t di = P.bk_pairs[off + (j * 3 + 1) * 64];
+        const uint32_t ui = P.bk_pairs[off + (j * 3 + 2) * 64];
+        acc = cx_sub(acc, cx_mul(cx_mul(W[ki], W[di]), W[ui]));
+      }
+      W[yi] = acc;
+    }
+  }
+  SPICEY_HD void k_scale(int tid) const {
+    SPICEY_NOUNROLL
+    for (int i = tid; i < P.n; i += T) W[P.nLU + i] = cx_mul(W[P.nLU + i], W[P.bk_d[i]]);
+  }
+  SPICEY_HD void z_record(int tid, int64_t fi) const {
+    const size_t slot = inst * (size_t)R.n_freq + (size_t)fi;
+    double *ov = R.out_v + slot * (size_t)P.nOut * 2;
+    SPICEY_NOUNROLL
+    for (int i = tid; i < P.nOut; i += T) {
+      const SpiceyCx v = volt(P.out_x[i]);
+      ov[2 * i] = v.re; ov[2 * i + 1] = v.im;
+    }
+    if (!R.out_i) return;
+    const int nCur = P.nR + P.nC + P.nL + P.nV;
+    double *oi = R.out_i + slot * (size_t)nCur * 2;
+    SPICEY_NOUNROLL
+    for (int i = tid; i < P.nR; i += T) {
+      const SpiceyCx cur = cx_mul(admittance((uint32_t)i), cx_sub(volt(P.R_a[i]), volt(P.R_b[i])));
+      oi[2 * i] = cur.re; oi[2 * i + 1] = cur.im;
+    }
+    SPICEY_NOUNROLL
+    for (int i = tid; i < P.nC; i += T) {
+      const SpiceyCx cur = cx_mul(admittance((uint32_t)(P.nR + i)), cx_sub(volt(P.C_a[i]), volt(P.C_b[i])));
+      oi[2 * (P.nR + i)] = cur.re; oi[2 * (P.nR + i) + 1] = cur.im;
+    }
+    SPICEY_NOUNROLL
+    for (int i = tid; i < P.nL; i += T) {
+      const SpiceyCx cur = cx_mul(admittance((uint32_t)(P.nR + P.nC + i)), cx_sub(volt(P.L_a[i]), volt(P.L_b[i])));
+      oi[2 * (P.nR + P.nC + i)] = cur.re; oi[2 * (P.nR + P.nC + i) + 1] = cur.im;
+    }
+    SPICEY_NOUNROLL
+    for (int i = tid; i < P.nV; i += T) {
+      const SpiceyCx cur = W[P.V_x[i]];
+      oi[2 * (P.nR + P.nC + P.nL + i)] = cur.re; oi[2 * (P.nR + P.nC + P.nL + i) + 1] = cur.im;
+    }
+  }
+};
+
+// One (instance, frequency) solve by one workgroup.  All control flow is workgroup-uniform.
+template <class Exec>
+SPICEY_HD void spicey_ac_solve(Exec &ex, const SpiceyProg &P, const SpiceyAcRun &R, SpiceyCx *W, int32_t *flags, int64_t slot) {
+  const size_t inst = (size_t)(slot / R.n_freq);
+  const int64_t fi = slot % R.n_freq;
+  const double two_pi = 2 * 3.141592653589793;
+  AcPhases<Exec> ph{P, R, W, flags, ex.threads(), inst, two_pi * R.freqs[fi]};
+  ex.phase(SPICEY_PH_PRO, [&](int tid) { if (tid == 0) flags[0] = 0; });
+  ex.phase(SPICEY_PH_B, [&](int tid) { ph.s_stamp(tid); });
+  for (int l = 0; l < P.nLevels; l++) {
+    if (P.lvl_slice[l] == P.lvl_slice[l + 1]) continue;
+    ex.phase(SPICEY_PH_U0, [&](int tid) { ph.u_level(tid, l); });
+  }
+  for (int l = P.nLevels - 1; l >= 0; l--) {
+    if (P.bk_lvl_slice[l] == P.bk_lvl_slice[l + 1]) continue;
+    ex.phase(SPICEY_PH_K0, [&](int tid) { ph.k_level(tid, l); });
+  }
+  ex.phase(SPICEY_PH_K0, [&](int tid) { ph.k_scale(tid); });
+  const int code = flags[0];
+  ex.phase(SPICEY_PH_Z, [&](int tid) {
+    if (code == 0) ph.z_record(tid, fi);
+    if (tid == 0) R.status[slot] = code;
+  });
+}

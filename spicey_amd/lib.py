@@ -20,7 +20,8 @@ _LIB = None
 
 EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "spicey_get_state", "spicey_last_solve_count",
            "spicey_last_kernel_ms", "spicey_get_info", "spicey_last_error", "spicey_destroy", "spicey_version",
-           "spicey_debug_phase_cycles"]
+           "spicey_debug_phase_cycles",
+           "spicey_ac_create", "spicey_ac_run", "spicey_ac_get_info", "spicey_ac_last_kernel_ms", "spicey_ac_last_error", "spicey_ac_destroy"]
 
 
 class SpiceyNativeError(RuntimeError):
@@ -59,6 +60,18 @@ def load():
     L.spicey_version.restype = C.c_char_p
     L.spicey_debug_phase_cycles.restype = C.c_int32
     L.spicey_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32]
+    L.spicey_ac_create.restype = C.c_int32
+    L.spicey_ac_create.argtypes = [C.POINTER(abi.SpiceyDesc), C.POINTER(abi.SpiceyOptions), C.POINTER(vp)]
+    L.spicey_ac_run.restype = C.c_int32
+    L.spicey_ac_run.argtypes = [vp, C.c_int64, f64p, f64p, f64p, f64p]
+    L.spicey_ac_get_info.restype = C.c_int32
+    L.spicey_ac_get_info.argtypes = [vp, C.POINTER(abi.SpiceyInfo)]
+    L.spicey_ac_last_kernel_ms.restype = C.c_double
+    L.spicey_ac_last_kernel_ms.argtypes = [vp]
+    L.spicey_ac_last_error.restype = C.c_char_p
+    L.spicey_ac_last_error.argtypes = [vp]
+    L.spicey_ac_destroy.restype = None
+    L.spicey_ac_destroy.argtypes = [vp]
     _LIB = L
     return L
 
@@ -160,6 +173,51 @@ class Handle:
             pass
 
 
+class AcHandle:
+    """spicey_ac_* of include/spicey_hip.h: AC sweep of n_inst instances of one topology."""
+
+    def __init__(self, flat: abi.FlatCircuit, device: int = 0, threads: int = 0, force_global: bool = False):
+        self.L = load()
+        self.flat = flat
+        opt = abi.SpiceyOptions()
+        opt.device, opt.threads, opt.force_global = int(device), int(threads), int(bool(force_global))
+        d = flat.desc()
+        h = C.c_void_p()
+        rc = self.L.spicey_ac_create(C.byref(d), C.byref(opt), C.byref(h))
+        if rc != abi.OK:
+            raise SpiceyNativeError(f"spicey_ac_create failed ({rc}): {self.L.spicey_ac_last_error(None).decode()}")
+        self.h = h
+
+    def info(self) -> dict:
+        info = abi.SpiceyInfo()
+        self.L.spicey_ac_get_info(self.h, C.byref(info))
+        return info.as_dict()
+
+    def run(self, freqs, vph, want_currents: bool = True) -> dict:
+        f = self.flat
+        ni, nf = f.n_inst, len(freqs)
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        # one phasor set for every instance, or one per instance
+        ph = np.ascontiguousarray(np.broadcast_to(np.asarray(vph, np.complex128).reshape(-1, f.nV), (ni, f.nV)))
+        out_v = np.zeros((ni, nf, f.n_out), np.complex128)
+        out_i = np.zeros((ni, nf, f.nR + f.nC + f.nL + f.nV), np.complex128) if want_currents else None
+        rc = self.L.spicey_ac_run(self.h, nf, _p(freqs, C.c_double), _p(ph.view(np.float64), C.c_double),
+                                  _p(out_v.view(np.float64), C.c_double), _p(out_i.view(np.float64), C.c_double) if want_currents else None)
+        detail = self.L.spicey_ac_last_error(self.h).decode() if rc != abi.OK else ""
+        return {"status": rc, "detail": detail, "out_v": out_v, "out_i": out_i, "kernel_ms": self.L.spicey_ac_last_kernel_ms(self.h)}
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.L.spicey_ac_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipBackend:
     """Backend interface used by spicey_amd.simulate: one handle per call (the reference API is stateless)."""
 
@@ -175,5 +233,13 @@ class HipBackend:
         try:
             self.info = h.info()
             return h.run(steps, dt, src, want_currents, want_iters)
+        finally:
+            h.close()
+
+    def run_ac(self, flat: abi.FlatCircuit, freqs, vph, want_currents: bool = True) -> dict:
+        h = AcHandle(flat, device=self.kw["device"], threads=self.kw["threads"], force_global=self.kw["force_global"])
+        try:
+            self.info = h.info()
+            return h.run(freqs, vph, want_currents)
         finally:
             h.close()

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../spicey_amd/csrc/symbolic.h"
+#include "../../spicey_amd/csrc/ac_exec.h"
 #include "../../spicey_amd/csrc/tran_exec.h"
 
 namespace {
@@ -175,5 +176,40 @@ extern "C" int32_t spicey_emul_resident(const SpiceyDesc *d, int32_t T, int32_t 
     for (int t = 0; t < T; t++) res_valid[(size_t)s * T + t] = (hr.res[((size_t)s * T + t) * 4] >> 16 & (SPICEY_R16_VALID << 8)) ? 1u : 0u;
   for (int p = 0; p < nPh; p++) { ph_cnt[p] = hp.ph_cnt[p]; st_cnt[p] = hr.st_cnt[p]; }
   meta[0] = hp.hdr.nLevels; meta[1] = hr.tail_first; meta[2] = hr.tail_n; meta[3] = hp.hdr.has16;
+  return SPICEY_OK;
+}
+
+// AC sweep through the same phase code as the HIP kernel (spicey_amd/csrc/ac_exec.h), one (instance, frequency) at a time.
+extern "C" int32_t spicey_emul_ac(const SpiceyDesc *d, int32_t T, int64_t n_freq, const double *freqs, const double *vph, double *out_v,
+                                  double *out_i, int32_t reverse, SpiceyInfo *info) {
+  SpiceyDesc dd = *d;
+  dd.nS = 0;
+  dd.nD = 0;
+  HostProgram hp;
+  std::string err;
+  int32_t rc = spicey_build_program(&dd, hp, err);
+  if (rc != SPICEY_OK) return rc;
+  SpiceyProg P = hp.bind(hp.blob.data());
+  if (info) {
+    memset(info, 0, sizeof(*info));
+    info->n_var = P.n; info->nnz_a = hp.nnzA; info->nnz_lu = P.nLU; info->n_levels = P.nLevels; info->threads = T;
+    info->n_cur = P.nR + P.nC + P.nL + P.nV; info->n_out = P.nOut;
+  }
+  if (hp.structurally_singular) return SPICEY_ERR_SINGULAR;
+  if (T <= 0 || (T & 63)) return SPICEY_ERR_BAD_DESC;
+  const size_t slots = (size_t)d->n_inst * (size_t)n_freq;
+  std::vector<int32_t> status(slots + 1);
+  SpiceyAcRun R{};
+  R.R_val = d->R_val; R.C_val = d->C_val; R.L_val = d->L_val;
+  R.freqs = freqs; R.vph = vph; R.out_v = out_v; R.out_i = out_i; R.gW = nullptr; R.status = status.data();
+  R.n_freq = n_freq; R.n_inst = d->n_inst;
+  std::vector<SpiceyCx> W((size_t)P.nW + 1);
+  int32_t flags[2] = {0, 0};
+  for (size_t s = 0; s < slots; s++) {
+    SeqExec ex{T, reverse != 0};
+    spicey_ac_solve(ex, P, R, W.data(), flags, (int64_t)s);
+  }
+  for (size_t s = 0; s < slots; s++)
+    if (status[s]) return status[s] == 1 ? SPICEY_ERR_SINGULAR : SPICEY_ERR_COMPLEX_DIV;
   return SPICEY_OK;
 }

@@ -27,6 +27,9 @@ def lib():
         L.spicey_emul_resident.restype = C.c_int32
         L.spicey_emul_resident.argtypes = [C.POINTER(abi.SpiceyDesc), C.c_int32, C.c_int32, C.c_int32, i32p, C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), i32p]
+        L.spicey_emul_ac.restype = C.c_int32
+        L.spicey_emul_ac.argtypes = [C.POINTER(abi.SpiceyDesc), C.c_int32, C.c_int64, f64p, f64p, f64p, f64p, C.c_int32,
+                                     C.POINTER(abi.SpiceyInfo)]
         _LIB = L
     return _LIB
 
@@ -64,6 +67,24 @@ class EmulBackend:
         self.solves = solves.value
         detail = f"singular at inst {err4[1]} step {err4[2]} iter {err4[3]}" if rc == abi.ERR_SINGULAR else ""
         return {"status": rc, "detail": detail, "out_v": out_v, "out_i": out_i, "iters": iters, "state": st}
+
+
+    def run_ac(self, flat: abi.FlatCircuit, freqs, vph, want_currents: bool = True) -> dict:
+        """AC sweep through spicey_amd/csrc/ac_exec.h (same interface as HipBackend.run_ac)."""
+        L = lib()
+        d = flat.desc()
+        ni, nf = flat.n_inst, len(freqs)
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        ph = np.ascontiguousarray(np.broadcast_to(np.asarray(vph, np.complex128).reshape(-1, flat.nV), (ni, flat.nV)))
+        out_v = np.zeros((ni, nf, flat.n_out), np.complex128)
+        out_i = np.zeros((ni, nf, flat.nR + flat.nC + flat.nL + flat.nV), np.complex128) if want_currents else None
+        info = abi.SpiceyInfo()
+        rc = L.spicey_emul_ac(C.byref(d), self.T, nf, _p(freqs, C.c_double), _p(ph.view(np.float64), C.c_double),
+                              _p(out_v.view(np.float64), C.c_double), _p(out_i.view(np.float64), C.c_double) if want_currents else None,
+                              1 if self.reverse else 0, C.byref(info))
+        self.info = info.as_dict()
+        detail = {1: "Singular matrix (complex)", 5: "Complex divide by ~0"}.get(rc, "")
+        return {"status": rc, "detail": detail, "out_v": out_v, "out_i": out_i}
 
 
 def symbolic(flat: abi.FlatCircuit):

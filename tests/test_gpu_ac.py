@@ -1,0 +1,101 @@
+"""GPU parity tests of the AC sweep: the HIP path (spicey_ac_* through libspicey_hip.so) against the oracle on the
+same inputs and against the reference-generated goldens.  Tolerance: |z - z_ref| <= 1e-9 |z_ref| + 1e-12 on every
+complex node voltage and element current (the transient bar of SURVEY.md §8(d) applied to complex magnitudes)."""
+import numpy as np
+import pytest
+
+from conftest import golden_netlist, load_golden
+from spicey_amd import abi, synth
+from spicey_amd import ac as sac
+from spicey_amd.netlist import parseNetlist
+from test_oracle_ac import ac_golden_netlist, cplx
+
+pytestmark = pytest.mark.gpu
+
+
+def cratio(got, ref, rtol=1e-9, atol=1e-12):
+    return np.abs(got - ref) / (rtol * np.abs(ref) + atol)
+
+
+@pytest.mark.parametrize("name", ["ac_readme", "ac_rlc", "ac_two_src", "ac_ladder30", "ac_mesh6"])
+def test_ac_hip_vs_oracle_and_golden(name, oracle_backend):
+    from spicey_amd.lib import HipBackend
+    g = load_golden(name)
+    ckt = parseNetlist(ac_golden_netlist(g))
+    flat = abi.flatten(ckt)
+    freqs, vph = np.array(g["freqs"]), cplx(g["vph"])
+    ref = oracle_backend.run_ac(flat, freqs, vph)
+    first = None
+    for kw in (dict(), dict(force_global=True), dict(threads=64)):
+        be = HipBackend(**kw)
+        got = be.run_ac(flat, freqs, vph)
+        assert got["status"] == 0, got["detail"]
+        assert (be.info["lds_bytes"] == 0) == bool(kw.get("force_global"))
+        assert cratio(got["out_v"], ref["out_v"]).max() <= 1.0 and cratio(got["out_i"], ref["out_i"]).max() <= 1.0
+        if first is None:
+            first = got
+        assert np.array_equal(got["out_v"], first["out_v"]) and np.array_equal(got["out_i"], first["out_i"])  # geometry-independent bits
+    names = ckt.nodes.rev
+    for i in range(1, ckt.nodes.count()):
+        assert cratio(first["out_v"][0, :, i - 1], cplx(g["V"][names[i]])).max() <= 1.0
+
+
+def test_ac_public_api_default_backend_reference_snapshot():
+    """simulate() with the default (HIP) backend reproduces the reference's inline snapshot of
+    tests/basics/basics01.test.ts / README.md character for character."""
+    from spicey_amd.simulate import simulate
+    g = load_golden("ac_readme")
+    out = simulate(golden_netlist(g))
+    assert out["tran"] is None and sac.formatAcResult(out["ac"]) == g["formatted"]
+    assert list(out["ac"]["elementCurrents"]) == g["keysI"]
+
+
+def test_ac_errors():
+    g = load_golden("ac_err_float")
+    with pytest.raises(sac.SingularComplexMatrixError):
+        sac.simulateAC(parseNetlist(golden_netlist(g)))
+    tiny = parseNetlist("* tiny\nV1 1 0 ac 1\nR1 1 0 1k\nC1 1 2 1e-12\nC2 2 0 1e-12\n.ac lin 2 1 2\n.end")
+    with pytest.raises(ZeroDivisionError, match="Complex divide by ~0"):
+        sac.simulateAC(tiny)
+    with pytest.raises(ValueError, match="R R1 must be > 0"):
+        sac.simulateAC(parseNetlist(golden_netlist(load_golden("ac_err_r0"))))
+
+
+def test_ac_baseline_sized_ladder_and_batch(oracle_backend):
+    """1001 unknowns (workspace 95 KB of LDS) at the golden's 16 frequencies; then 8 swept instances x 16 frequencies
+    in one launch against the oracle."""
+    from spicey_amd.lib import HipBackend
+    g = load_golden("ac_rc1000")
+    ckt = parseNetlist(ac_golden_netlist(g))
+    flat = abi.flatten(ckt)
+    be = HipBackend()
+    got = be.run_ac(flat, np.array(g["freqs"]), cplx(g["vph"]))
+    assert got["status"] == 0 and be.info["n_var"] == 1001 and be.info["lds_bytes"] > 90000
+    names = ckt.nodes.rev
+    col = {names[i]: i - 1 for i in range(1, ckt.nodes.count())}
+    for k, v in g["V"].items():
+        assert cratio(got["out_v"][0, :, col[k]], cplx(v)).max() <= 1.0, k
+    elem = [e.name for e in ckt.R] + [e.name for e in ckt.C] + [e.name for e in ckt.L] + [e.name for e in ckt.V]
+    for k, v in g["I"].items():
+        assert cratio(got["out_i"][0, :, elem.index(k)], cplx(v)).max() <= 1.0, k
+    flat8, _, _, _ = synth.chain_batch("rc_ladder", 300, range(1, 9), tran=".tran 1e-6 3e-5")
+    freqs = np.array(sac.logspace(1e3, 1e8, 3))
+    ref = oracle_backend.run_ac(flat8, freqs, np.array([1.0 + 0.0j]))
+    got = HipBackend().run_ac(flat8, freqs, np.array([1.0 + 0.0j]))
+    assert got["status"] == 0 and got["out_v"].shape == (8, len(freqs), 300)
+    assert cratio(got["out_v"], ref["out_v"]).max() <= 1.0 and cratio(got["out_i"], ref["out_i"]).max() <= 1.0
+
+
+def test_ac_large_mesh_global_workspace(oracle_backend):
+    """rcd_mesh(34x34): 1157 unknowns but ~25 000 L+U entries -> the complex workspace (16 B per entry) leaves LDS."""
+    from spicey_amd.lib import HipBackend
+    text = "\n".join(ln + " ac 1" if ln.startswith("V1 ") else ln for ln in synth.rcd_mesh(34, seed=11, tran=".ac dec 2 1e5 1e8").split("\n"))
+    ckt = parseNetlist(text)
+    flat = abi.flatten(ckt)
+    freqs = np.array(sac.buildFrequencyArray(**ckt.analyses["ac"]))
+    vph = sac.source_phasors(ckt)
+    be = HipBackend()
+    got = be.run_ac(flat, freqs, vph)
+    assert got["status"] == 0 and be.info["lds_bytes"] == 0
+    ref = oracle_backend.run_ac(flat, freqs, vph)
+    assert cratio(got["out_v"], ref["out_v"]).max() <= 1.0 and cratio(got["out_i"], ref["out_i"]).max() <= 1.0

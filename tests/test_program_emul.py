@@ -252,3 +252,67 @@ def test_product_does_not_touch_oracle():
                 text = open(os.path.join(root, f)).read()
                 assert not re.search(r"(from|import)\s+oracle|oracle/|pyoracle|liboracle|tests/emul|pyemul", text.replace("tests/emul)", "")) \
                     or f in ("tran_exec.h",), (root, f)
+
+
+# ---- AC sweep: the device phase code (spicey_amd/csrc/ac_exec.h) on the CPU against the oracle ---------------------
+AC_GOLDENS = ["ac_readme", "ac_rlc", "ac_two_src", "ac_ladder30", "ac_mesh6"]
+
+
+def _ac_inputs(name):
+    from test_oracle_ac import ac_golden_netlist, cplx
+    g = load_golden(name)
+    ckt = parseNetlist(ac_golden_netlist(g))
+    return g, ckt, abi.flatten(ckt), np.array(g["freqs"]), cplx(g["vph"])
+
+
+def cratio(got, ref, rtol=1e-9, atol=1e-12):
+    return np.abs(got - ref) / (rtol * np.abs(ref) + atol)
+
+
+@pytest.mark.parametrize("name", AC_GOLDENS)
+def test_ac_program_matches_reference_goldens(name, oracle_backend):
+    """Sparse complex LU in the fixed pivot order vs the reference's dense partial-pivoting solve: 1e-9 relative on
+    every complex node voltage and element current; thread order within a phase must not matter (race detector)."""
+    from test_oracle_ac import cplx
+    g, ckt, flat, freqs, vph = _ac_inputs(name)
+    ref = oracle_backend.run_ac(flat, freqs, vph)
+    first = None
+    for T, rev in ((64, False), (256, True), (128, False)):
+        got = EmulBackend(1, T, rev).run_ac(flat, freqs, vph)
+        assert got["status"] == 0
+        assert cratio(got["out_v"], ref["out_v"]).max() <= 1.0 and cratio(got["out_i"], ref["out_i"]).max() <= 1.0
+        if first is None:
+            first = got
+        assert np.array_equal(got["out_v"], first["out_v"]) and np.array_equal(got["out_i"], first["out_i"])
+    # and straight against the reference's own numbers
+    names = ckt.nodes.rev
+    for i in range(1, ckt.nodes.count()):
+        assert cratio(first["out_v"][0, :, i - 1], cplx(g["V"][names[i]])).max() <= 1.0
+
+
+def test_ac_program_public_api_and_errors(oracle_backend):
+    from spicey_amd import ac as sac
+    g, ckt, flat, freqs, vph = _ac_inputs("ac_readme")
+    res = sac.simulateAC(ckt, backend=EmulBackend(1, 64))
+    assert sac.formatAcResult(res) == g["formatted"]  # the reference's inline snapshot, through the sparse program
+    gf = load_golden("ac_err_float")
+    with pytest.raises(sac.SingularComplexMatrixError):
+        sac.simulateAC(parseNetlist(golden_netlist(gf)), backend=EmulBackend(1, 64))
+    # a node reached only through tiny admittances: |pivot|^2 < 1e-15 -> "Complex divide by ~0" like Complex.div
+    tiny = parseNetlist("* tiny\nV1 1 0 ac 1\nR1 1 0 1k\nC1 1 2 1e-12\nC2 2 0 1e-12\n.ac lin 2 1 2\n.end")
+    with pytest.raises(ZeroDivisionError, match="Complex divide by ~0"):
+        sac.simulateAC(tiny, backend=EmulBackend(1, 64))
+    with pytest.raises(ZeroDivisionError, match="Complex divide by ~0"):
+        sac.simulateAC(tiny, backend=oracle_backend)
+
+
+def test_ac_program_batched_instances(oracle_backend):
+    """Parameter-swept instances x frequencies: every pair is its own solve."""
+    flat, _, _, _ = synth.chain_batch("rc_ladder", 40, range(1, 5), tran=".tran 1e-6 3e-5")
+    freqs = np.array(sac_freqs := [1e3, 3e4, 1e6, 2.5e7])
+    vph = np.array([1.0 + 0.0j])
+    ref = oracle_backend.run_ac(flat, freqs, vph)
+    got = EmulBackend(1, 64).run_ac(flat, freqs, vph)
+    assert got["status"] == ref["status"] == 0 and got["out_v"].shape == (4, 4, 40)
+    assert cratio(got["out_v"], ref["out_v"]).max() <= 1.0 and cratio(got["out_i"], ref["out_i"]).max() <= 1.0
+    assert not np.array_equal(got["out_v"][0], got["out_v"][1])
