@@ -127,6 +127,54 @@ def formatTranResult(tran: Optional[dict]) -> str:
     return "\n".join(lines)
 
 
+def spiceyTranToVGraphs(tranResult: Optional[dict], ckt: ParsedCircuit, simulation_experiment_id: str) -> List[dict]:
+    """/root/reference/lib/formatting/formatToVGraph.ts:11-39: one circuit-json
+    `simulation_transient_voltage_graph` per recorded node.  `timestamps_ms` is computed once for all graphs (one
+    vectorised multiply of the typed time axis; the reference maps the array again for every node)."""
+    tran = ckt.analyses.get("tran")
+    if not tranResult or not tran:
+        return []
+    ts_ms = (np.asarray(tranResult["times"], dtype=np.float64) * 1000).tolist()
+    graphs = []
+    for node_name, levels in tranResult["nodeVoltages"].items():
+        graphs.append({
+            "type": "simulation_transient_voltage_graph",
+            "simulation_transient_voltage_graph_id": f"stvg_{simulation_experiment_id}_{node_name}",
+            "simulation_experiment_id": simulation_experiment_id,
+            "timestamps_ms": ts_ms,
+            "voltage_levels": levels if isinstance(levels, list) else np.asarray(levels).tolist(),
+            "time_per_step": tran["dt"] * 1000,
+            "start_time_ms": 0,
+            "end_time_ms": tran["tstop"] * 1000,
+            "name": f"V({node_name})",
+        })
+    return graphs
+
+
+def eecEngineTranToVGraphs(tranResult: dict, ckt: ParsedCircuit, simulation_experiment_id: str) -> List[dict]:
+    """formatToVGraph.ts:41-65: the same graphs from an ngspice-style {time_s, voltages} result."""
+    tran = ckt.analyses.get("tran")
+    if not tran:
+        return []
+    ts_ms = (np.asarray(tranResult["time_s"], dtype=np.float64) * 1000).tolist()
+    return [{
+        "type": "simulation_transient_voltage_graph",
+        "simulation_transient_voltage_graph_id": f"stvg_{simulation_experiment_id}_{node_name}_eec",
+        "simulation_experiment_id": simulation_experiment_id,
+        "timestamps_ms": ts_ms,
+        "voltage_levels": levels,
+        "time_per_step": tran["dt"] * 1000,
+        "start_time_ms": 0,
+        "end_time_ms": tran["tstop"] * 1000,
+        "name": f"V({node_name}) (ngspice)",
+    } for node_name, levels in js_ordered_items(tranResult["voltages"])]
+
+
+def js_ordered_items(d: dict):
+    """`for (const k in obj)`: integer-like keys first, ascending, then insertion order."""
+    return [(k, d[k]) for k in js_object_key_order(list(d.keys()))]
+
+
 def _to_precision6_array(x: np.ndarray) -> np.ndarray:
     """Number.prototype.toPrecision(6) for a whole array (object array of str)."""
     x = np.asarray(x, dtype=np.float64)

@@ -144,3 +144,18 @@ def test_format_tran_result_vectorised_matches_scalar():
     got = _to_precision6_array(x)
     for v, g in zip(x, got):
         assert g == _to_precision6(float(v)), (v, g, _to_precision6(float(v)))
+
+
+@pytest.mark.parametrize("name", ["two_probes", "switch_vt_vh"])
+def test_vgraph_formatter_matches_reference(name, oracle_backend):
+    """spiceyTranToVGraphs / eecEngineTranToVGraphs (formatToVGraph.ts:11-65) against the reference's own output."""
+    from spicey_amd.simulate import eecEngineTranToVGraphs, spiceyTranToVGraphs
+    g = load_golden("vgraph_" + name)
+    ckt = parseNetlist(golden_netlist(g))
+    res = simulateTRAN(ckt, backend=oracle_backend)
+    graphs = spiceyTranToVGraphs(res, ckt, "exp_1")
+    assert json.loads(json.dumps(graphs)) == g["graphs"]  # keys, ids, names, bit-identical doubles (shortest round-trip)
+    assert [list(a) for a in graphs] == [list(b) for b in g["graphs"]]  # and the reference's key order
+    eec = eecEngineTranToVGraphs({"time_s": [0, 1e-3, 2.5e-3], "voltages": {"out": [0, 1.5, 3.25], "2": [1, 2, 3]}}, ckt, "exp_2")
+    assert json.loads(json.dumps(eec)) == g["eec"] and [e["name"] for e in eec] == [e["name"] for e in g["eec"]]
+    assert spiceyTranToVGraphs(None, ckt, "x") == []

@@ -44,6 +44,7 @@ AC_FILES = [
     "utils/logspace.ts",
     "analysis/simulateAC.ts",
     "formatting/formatAcResult.ts",
+    "formatting/formatToVGraph.ts",
 ]
 
 
@@ -108,6 +109,10 @@ def erase(src: str, rel: str) -> str:
         s = re.sub(r"function formatTranResult\(\s*tran: \{[\s\S]*?\} \| null,\s*\)",
                    "function formatTranResult(tran)", s)
 
+    if rel.endswith("formatToVGraph.ts"):  # multi-line typed parameter lists with generic return types
+        s = re.sub(r"export function (\w+)\(\s*tranResult: [^,]+,\s*ckt: ParsedCircuit,[^\n]*\n\s*simulation_experiment_id: string,\s*\): SimulationTransientVoltageGraph\[\] \{",
+                   r"export function \1(tranResult, ckt, simulation_experiment_id) {", s)
+        s = re.sub(r"const graphs: SimulationTransientVoltageGraph\[\] = \[\]", "const graphs = []", s)
     if rel.endswith("formatAcResult.ts"):
         s = re.sub(r"function formatAcResult\(\s*ac: \{[\s\S]*?\} \| null,\s*\)", "function formatAcResult(ac)", s)
     if rel.endswith("simulateAC.ts"):  # object-typed return annotation

@@ -17,6 +17,7 @@ export const SPICEY_ERR_SINGULAR = 1
 export const SPICEY_ERR_BAD_DESC = 2
 export const SPICEY_ERR_HIP = 3
 export const SPICEY_ERR_NO_DEVICE = 4
+export const SPICEY_ERR_COMPLEX_DIV = 5
 
 const libPath = process.env.SPICEY_HIP_LIB ?? `${import.meta.dir}/../spicey_amd/libspicey_hip.so`
 
@@ -31,6 +32,10 @@ const { symbols: C } = dlopen(libPath, {
   spicey_last_solve_count: { args: [FFIType.ptr], returns: FFIType.i64 },
   spicey_destroy: { args: [FFIType.ptr], returns: FFIType.void },
   spicey_version: { args: [], returns: FFIType.ptr },
+  spicey_ac_create: { args: [FFIType.ptr, FFIType.ptr, FFIType.ptr], returns: FFIType.i32 },
+  spicey_ac_run: { args: [FFIType.ptr, FFIType.i64, FFIType.ptr, FFIType.ptr, FFIType.ptr, FFIType.ptr], returns: FFIType.i32 },
+  spicey_ac_last_error: { args: [FFIType.ptr], returns: FFIType.ptr },
+  spicey_ac_destroy: { args: [FFIType.ptr], returns: FFIType.void },
 })
 
 /** SoA view of one ParsedCircuit (parseNetlist.ts:85-105); node ids are the reference's (0 = ground). */
@@ -115,6 +120,41 @@ export function runTransientNative(f: FlatCircuit, steps: number, dt: number, sr
     return { outV, outI, iters, state }
   } finally {
     C.spicey_destroy(h)
+  }
+}
+
+export type NativeAcResult = {
+  outV: Float64Array // [nFreq][nNodes][2] (re, im)
+  outI: Float64Array // [nFreq][nR+nC+nL+nV][2], order R, C, L, V
+}
+
+/** One AC sweep on the GPU: every frequency is an independent complex solve (simulateAC.ts:80-126), one launch.
+ *  vph = [nV][2] source phasors.  Throws the reference's Error messages (solveComplex.ts:28, Complex.ts:42). */
+export function runAcNative(f: FlatCircuit, freqs: Float64Array, vph: Float64Array): NativeAcResult {
+  const { buf, keep } = packDesc(f)
+  const opt = new ArrayBuffer(SpiceyOptionsLayout.size)
+  const hOut = new BigUint64Array(1)
+  let rc = C.spicey_ac_create(ptr(buf), ptr(opt), ptr(hOut))
+  void keep
+  if (rc !== SPICEY_OK) {
+    const p = C.spicey_ac_last_error(null)
+    throw new Error(`spicey_ac_create failed (${rc}): ${p ? new CString(p).toString() : ""}`)
+  }
+  const h = Number(hOut[0]) as unknown as Pointer
+  try {
+    const nCur = f.R.n1.length + f.C.n1.length + f.L.n1.length + f.V.n1.length
+    const outV = new Float64Array(freqs.length * Math.max(f.nNodes, 1) * 2)
+    const outI = new Float64Array(freqs.length * Math.max(nCur, 1) * 2)
+    rc = C.spicey_ac_run(h, BigInt(freqs.length), freqs.length ? ptr(freqs) : null, vph.length ? ptr(vph) : null, ptr(outV), ptr(outI))
+    if (rc === SPICEY_ERR_SINGULAR) throw new Error("Singular matrix (complex)")
+    if (rc === SPICEY_ERR_COMPLEX_DIV) throw new Error("Complex divide by ~0")
+    if (rc !== SPICEY_OK) {
+      const p = C.spicey_ac_last_error(h)
+      throw new Error(`spicey_ac_run failed (${rc}): ${p ? new CString(p).toString() : ""}`)
+    }
+    return { outV, outI }
+  } finally {
+    C.spicey_ac_destroy(h)
   }
 }
 
