@@ -32,8 +32,8 @@ template <bool LDS>
 __global__ void __launch_bounds__(1024) spicey_ac_kernel(SpiceyProg P, SpiceyAcRun R) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int32_t flags[2];
-  const int64_t slot = (int64_t)blockIdx.x;
-  SpiceyCx *W = LDS ? (SpiceyCx *)smem : (SpiceyCx *)R.gW + (size_t)slot * (size_t)P.nW;
+  const int64_t slot = R.slot_base + (int64_t)blockIdx.x;
+  SpiceyCx *W = LDS ? (SpiceyCx *)smem : (SpiceyCx *)R.gW + (size_t)blockIdx.x * (size_t)P.nW;
   GpuAcExec ex;
   spicey_ac_solve(ex, P, R, W, flags, slot);
 }
@@ -121,7 +121,8 @@ extern "C" int32_t spicey_ac_create(const SpiceyDesc *desc, const SpiceyOptions 
   h->lds_bytes = (size_t)P.nW * sizeof(SpiceyCx);
   h->lds = !h->opt.force_global && h->lds_bytes + 64 <= SPICEY_LDS_MAX;
   const int n = P.n;
-  h->T = h->opt.threads > 0 ? h->opt.threads : (n <= 48 ? 64 : n <= 160 ? 128 : n <= 1200 ? 256 : n <= 4000 ? 512 : 1024);
+  // measured on rc_ladder(1000) x 201 frequencies: 256 / 512 / 1024 threads = 62 / 43 / 35 us per sweep (one wave of workgroups)
+  h->T = h->opt.threads > 0 ? h->opt.threads : (n <= 48 ? 64 : n <= 160 ? 128 : n <= 400 ? 256 : 1024);
   if (h->T > 1024 || (h->T & 63) || h->T < 64) { h->err = "threads must be a multiple of 64 in [64, 1024]"; return fail(SPICEY_ERR_BAD_DESC); }
   if (hipMalloc(&h->d_blob, h->hp.blob.size()) != hipSuccess ||
       hipMemcpy(h->d_blob, h->hp.blob.data(), h->hp.blob.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -181,7 +182,10 @@ extern "C" int32_t spicey_ac_run(SpiceyAcHandle *h, int64_t n_freq, const double
     ACCHK(h, hipMalloc((void **)&d_ov, std::max<size_t>(1, slots * (size_t)P.nOut * 2) * sizeof(double)));
     if (out_i) ACCHK(h, hipMalloc((void **)&d_oi, std::max<size_t>(1, slots * (size_t)nCur * 2) * sizeof(double)));
     ACCHK(h, hipMalloc((void **)&d_status, slots * sizeof(int32_t)));
-    if (!h->lds) ACCHK(h, hipMalloc((void **)&d_gW, slots * (size_t)P.nW * sizeof(SpiceyCx)));
+    // global workspace: one slice per workgroup of a launch; sweeps whose slices would exceed 16 GiB run in chunks
+    const size_t slice = (size_t)P.nW * sizeof(SpiceyCx);
+    const size_t chunk = h->lds ? slots : std::min(slots, std::max<size_t>(1, ((size_t)16 << 30) / slice));
+    if (!h->lds) ACCHK(h, hipMalloc((void **)&d_gW, chunk * slice));
     ACCHK(h, hipMemcpyAsync(d_f, freqs, (size_t)n_freq * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (P.nV > 0) ACCHK(h, hipMemcpyAsync(d_ph, vph, (size_t)h->n_inst * P.nV * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     SpiceyAcRun R{};
@@ -189,15 +193,19 @@ extern "C" int32_t spicey_ac_run(SpiceyAcHandle *h, int64_t n_freq, const double
     R.freqs = d_f; R.vph = d_ph; R.out_v = d_ov; R.out_i = d_oi; R.gW = d_gW; R.status = d_status;
     R.n_freq = n_freq; R.n_inst = h->n_inst;
     ACCHK(h, hipEventRecord(h->ev0, h->stream));
-    if (h->lds) {
-      auto kern = spicey_ac_kernel<true>;
-      if (h->lds_bytes > 48 * 1024)
-        ACCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-      hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(h->T), h->lds_bytes, h->stream, h->dprog, R);
-    } else {
-      hipLaunchKernelGGL(spicey_ac_kernel<false>, dim3((unsigned)slots), dim3(h->T), 0, h->stream, h->dprog, R);
+    for (size_t base = 0; base < slots; base += chunk) {
+      const unsigned grid = (unsigned)std::min(chunk, slots - base);
+      R.slot_base = (int64_t)base;
+      if (h->lds) {
+        auto kern = spicey_ac_kernel<true>;
+        if (h->lds_bytes > 48 * 1024)
+          ACCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(h->T), h->lds_bytes, h->stream, h->dprog, R);
+      } else {
+        hipLaunchKernelGGL(spicey_ac_kernel<false>, dim3(grid), dim3(h->T), 0, h->stream, h->dprog, R);
+      }
+      ACCHK(h, hipGetLastError());
     }
-    ACCHK(h, hipGetLastError());
     ACCHK(h, hipEventRecord(h->ev1, h->stream));
     ACCHK(h, hipMemcpyAsync(status.data(), d_status, slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     ACCHK(h, hipMemcpyAsync(out_v, d_ov, slots * (size_t)P.nOut * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));

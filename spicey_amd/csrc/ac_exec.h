@@ -23,6 +23,7 @@ struct SpiceyAcRun {
   double *gW;                           // [n_workgroups][nW][2] global workspace, or null when the workspace is in LDS
   int32_t *status;                      // [n_inst * n_freq] 0 ok, 1 singular, 5 complex divide by ~0
   int64_t n_freq;
+  int64_t slot_base;                    // first (instance, frequency) slot of this launch (large sweeps run in chunks)
   int32_t n_inst;
 };
 
