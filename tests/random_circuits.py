@@ -1,0 +1,79 @@
+"""Seeded random netlists for property tests (test infrastructure): connected R/C/L/V/D/S mixes in the reference's
+netlist dialect.  Every circuit has a resistive spanning tree to ground (so the DC operating matrix is regular) plus
+random extra elements, including floating capacitors / inductors, several sources and switches with random control
+pairs."""
+import random
+
+
+def random_netlist(seed: int, max_nodes: int = 10) -> str:
+    rnd = random.Random(seed)
+    n = rnd.randint(2, max_nodes)
+    nodes = [f"n{i}" for i in range(1, n + 1)]
+    lines = [f"* random circuit seed {seed}"]
+    has_d = rnd.random() < 0.6
+    has_s = rnd.random() < 0.4
+    if has_d:
+        lines.append(f".model DM D(Is={rnd.choice(['1e-14', '2e-12', '5e-15'])} N={rnd.choice(['1', '1.5', '2'])})")
+    if has_s:
+        lines.append(f".model SW1 SW(Ron={rnd.choice(['1', '0.5', '10'])} Roff={rnd.choice(['1e6', '1e9'])} Vt={rnd.choice(['1', '2.5'])} Vh={rnd.choice(['0', '0.2', '0.5'])})")
+    k = 0
+
+    def name(p):
+        nonlocal k
+        k += 1
+        return f"{p}{k}"
+
+    def val(lo, hi):
+        import math
+        return f"{math.exp(rnd.uniform(math.log(lo), math.log(hi))):.6g}"
+
+    # sources: 1-2, each from its own node to ground (no source loops)
+    nsrc = rnd.randint(1, min(2, n))
+    src_nodes = rnd.sample(nodes, nsrc)
+    for sn in src_nodes:
+        kind = rnd.random()
+        if kind < 0.45:
+            w = f"PULSE(0 {rnd.choice(['5', '3.3', '-2', '12'])} {rnd.choice(['0', '2e-6'])} 1e-6 1e-6 {rnd.choice(['5e-6', '8e-6'])} {rnd.choice(['1.2e-5', '2e-5'])})"
+        elif kind < 0.75:
+            w = f"PWL(0 0 4e-6 {rnd.choice(['5', '-3'])} 9e-6 {rnd.choice(['1', '0'])} 1.6e-5 {rnd.choice(['4', '6'])})"
+        else:
+            w = f"dc {rnd.choice(['5', '1.5', '-3'])}"
+        lines.append(f"{name('V')} {sn} 0 {w}")
+    # resistive spanning tree over {ground} + nodes
+    order = nodes[:]
+    rnd.shuffle(order)
+    placed = ["0"]
+    for nd in order:
+        lines.append(f"{name('R')} {nd} {rnd.choice(placed)} {val(10, 1e5)}")
+        placed.append(nd)
+
+    def pair():
+        a = rnd.choice(nodes)
+        b = rnd.choice(["0"] + nodes)
+        while b == a:
+            b = rnd.choice(["0"] + nodes)
+        return a, b
+
+    for _ in range(rnd.randint(0, n)):
+        a, b = pair()
+        lines.append(f"{name('R')} {a} {b} {val(10, 1e5)}")
+    for _ in range(rnd.randint(1, n + 1)):
+        a, b = pair()
+        lines.append(f"{name('C')} {a} {b} {val(1e-10, 1e-6)}")
+    for _ in range(rnd.randint(0, max(1, n // 3))):
+        a, b = pair()
+        if a in src_nodes and b in src_nodes + ["0"]:
+            continue  # an ideal inductor straight across ideal sources is singular at t = 0 in any MNA
+        lines.append(f"{name('L')} {a} {b} {val(1e-6, 1e-2)}")
+    if has_d:
+        for _ in range(rnd.randint(1, max(1, n // 2))):
+            a, b = pair()
+            lines.append(f"{name('D')} {a} {b} DM")
+    if has_s:
+        for _ in range(rnd.randint(1, 2)):
+            a, b = pair()
+            c, d = pair()
+            lines.append(f"{name('S')} {a} {b} {c} {d} SW1")
+    lines.append(f".tran 1e-6 {rnd.choice(['2e-5', '1.5e-5', '3e-5'])}")
+    lines.append(".end")
+    return "\n".join(lines)

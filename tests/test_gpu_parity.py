@@ -331,3 +331,34 @@ def test_long_run_golden_full_configs(hip):
         for s, vec in g["I_steps"].items():
             assert tol_ratio(got["out_i"][0][int(s)], farr(vec)).max() <= 1.0, (name, s)
         assert tol_ratio(got["state"]["C_vprev"][0], farr(g["state"]["C_vPrev"])).max() <= 1.0
+
+
+def test_random_circuits_on_gpu(oracle_backend):
+    """Seeded random R/C/L/V/D/S netlists (tests/random_circuits.py) through the default GPU path against the oracle.
+    Left out: seeds whose switch iteration hits the cap of 20 (the trajectory after a non-converged step hangs on the
+    last bit) and the three whose fp64 conditioning leaves < 20x margin on the CPU emulation of the same program
+    (tests/test_program_emul.py arbitrates those in extended precision)."""
+    from random_circuits import random_netlist
+    from spicey_amd.lib import HipBackend
+    skip = {36, 116, 117, 182, 185, 192, 59, 76, 190}
+    ran = multi = 0
+    for seed in range(200):
+        if seed in skip:
+            continue
+        ckt = parseNetlist(random_netlist(seed))
+        dt, steps = abi.computeEffectiveTimeStep(ckt.analyses["tran"]["dt"], ckt.analyses["tran"]["tstop"])
+        flat = abi.flatten(ckt)
+        src = abi.source_table(ckt, dt, steps)
+        ref = oracle_backend.run(flat, steps, dt, src)
+        got = HipBackend().run(flat, steps, dt, src)
+        assert got["status"] == ref["status"] == 0, (seed, got["detail"])
+        assert np.array_equal(got["iters"], ref["iters"]), seed
+        assert tol_ratio(got["out_v"], ref["out_v"]).max() <= 1.0, seed
+        fin = np.isfinite(ref["out_i"])
+        assert np.array_equal(fin, np.isfinite(got["out_i"])) and tol_ratio(got["out_i"][fin], ref["out_i"][fin]).max() <= 1.0, seed
+        for k in ("C_vprev", "L_iprev", "D_vdprev"):
+            assert tol_ratio(got["state"][k], ref["state"][k]).max() <= 1.0, (seed, k)
+        assert np.array_equal(got["state"]["S_ison"], ref["state"]["S_ison"]), seed
+        ran += 1
+        multi += int(ref["iters"].max() > 1)
+    assert ran == 191 and multi > 20
