@@ -187,6 +187,21 @@ double spicey_ac_last_kernel_ms(SpiceyAcHandle *h);
 const char *spicey_ac_last_error(SpiceyAcHandle *h);
 void spicey_ac_destroy(SpiceyAcHandle *h);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Result formatting fast path (host code, no GPU): the CSV text of
+ *   formatTranResult(tran)       /root/reference/lib/formatting/formatTranResult.ts:1-23
+ * straight from the typed arrays spicey_run filled.  Every number is Number.prototype.toPrecision(6) exactly as
+ * ECMA-262 defines it (ties to the larger digit string, exponential notation for e < -6 or e >= 6).
+ *   times    [n_points]
+ *   values   [n_points][stride]; series j is column cols[j] (the caller applies the JS key order / probe filter)
+ *   header   first line, e.g. "t(s), 1:V, 2:V"
+ * Returns the byte length of the text (lines joined by "\n", no trailing newline) and writes it when out_cap
+ * suffices (call with out = NULL to size the buffer); -1 on bad arguments. */
+int64_t spicey_format_tran(int64_t n_points, int32_t n_series, const double *times, const double *values, int64_t stride,
+                           const int32_t *cols, const char *header, char *out, int64_t out_cap);
+/* toPrecision(6) of one double into dst (>= 32 bytes, not NUL-terminated); returns the length. */
+int32_t spicey_to_precision6(double x, char *dst32);
+
 #ifdef __cplusplus
 }
 #endif

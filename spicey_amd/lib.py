@@ -21,7 +21,8 @@ _LIB = None
 EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "spicey_get_state", "spicey_last_solve_count",
            "spicey_last_kernel_ms", "spicey_get_info", "spicey_last_error", "spicey_destroy", "spicey_version",
            "spicey_debug_phase_cycles",
-           "spicey_ac_create", "spicey_ac_run", "spicey_ac_get_info", "spicey_ac_last_kernel_ms", "spicey_ac_last_error", "spicey_ac_destroy"]
+           "spicey_ac_create", "spicey_ac_run", "spicey_ac_get_info", "spicey_ac_last_kernel_ms", "spicey_ac_last_error", "spicey_ac_destroy",
+           "spicey_format_tran", "spicey_to_precision6"]
 
 
 class SpiceyNativeError(RuntimeError):
@@ -72,6 +73,10 @@ def load():
     L.spicey_ac_last_error.argtypes = [vp]
     L.spicey_ac_destroy.restype = None
     L.spicey_ac_destroy.argtypes = [vp]
+    L.spicey_format_tran.restype = C.c_int64
+    L.spicey_format_tran.argtypes = [C.c_int64, C.c_int32, f64p, f64p, C.c_int64, i32p, C.c_char_p, C.c_char_p, C.c_int64]
+    L.spicey_to_precision6.restype = C.c_int32
+    L.spicey_to_precision6.argtypes = [C.c_double, C.c_char_p]
     _LIB = L
     return L
 
@@ -171,6 +176,31 @@ class Handle:
             self.close()
         except Exception:
             pass
+
+
+def format_tran_native(times: np.ndarray, values: np.ndarray, cols, header: str) -> str:
+    """spicey_format_tran: CSV text of formatTranResult from a [n_points][stride] matrix (host code, multi-threaded)."""
+    L = load()
+    times = np.ascontiguousarray(times, dtype=np.float64)
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    if values.ndim != 2 or values.shape[0] != len(times):
+        raise ValueError("values must be [n_points][stride]")
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    hdr = header.encode("utf-8")
+    need = L.spicey_format_tran(len(times), len(cols), _p(times, C.c_double), _p(values, C.c_double), values.shape[1],
+                                _p(cols, C.c_int32), hdr, None, 0)
+    if need < 0:
+        raise SpiceyNativeError("spicey_format_tran: bad arguments")
+    buf = C.create_string_buffer(int(need) + 1)
+    L.spicey_format_tran(len(times), len(cols), _p(times, C.c_double), _p(values, C.c_double), values.shape[1],
+                         _p(cols, C.c_int32), hdr, buf, need)
+    return buf.raw[:need].decode("utf-8")
+
+
+def to_precision6_native(x: float) -> str:
+    buf = C.create_string_buffer(40)
+    n = load().spicey_to_precision6(float(x), buf)
+    return buf.raw[:n].decode("ascii")
 
 
 class AcHandle:

@@ -108,20 +108,30 @@ def simulate(netlist_text: str, backend=None) -> dict:
 
 def formatTranResult(tran: Optional[dict]) -> str:
     """/root/reference/lib/formatting/formatTranResult.ts:1-23 (toPrecision(6) CSV), straight from the typed
-    result arrays: every column is formatted with one vectorised pass (SURVEY.md §8(f) rank 3 — after the solve is
-    fast, per-value string formatting dominates end-to-end time for large runs)."""
+    result arrays (SURVEY.md §8(f) rank 3 — after the solve is fast, per-value string formatting dominates end-to-end
+    time for large runs).  Rectangular results go through the native formatter of libspicey_hip.so
+    (spicey_format_tran: host code, multi-threaded, ~50x the numpy path below); ragged ones (the reference skips
+    missing values) and builds without the library use the vectorised numpy path — both produce the same text."""
     if not tran:
         return "No TRAN analysis.\n"
     nodes = list(tran["nodeVoltages"].keys())
     n = len(tran["times"])
+    header = ", ".join(["t(s)"] + [f"{nm}:V" for nm in nodes])
+    series = [np.asarray(tran["nodeVoltages"][name], dtype=np.float64) for name in nodes]
+    if n and all(len(a) >= n for a in series):
+        try:
+            from .lib import SpiceyNativeError, format_tran_native
+            mat = np.stack([a[:n] for a in series], axis=1) if series else np.zeros((n, 0))
+            return format_tran_native(np.asarray(tran["times"], dtype=np.float64), mat, np.arange(len(series)), header)
+        except (ImportError, OSError, SpiceyNativeError):
+            pass
     cols = [_to_precision6_array(np.asarray(tran["times"], dtype=np.float64))]
-    for name in nodes:
-        series = np.asarray(tran["nodeVoltages"][name], dtype=np.float64)
-        col = _to_precision6_array(series[:n])
+    for a in series:
+        col = _to_precision6_array(a[:n])
         if len(col) < n:  # the reference skips missing values (`if (value == null) continue`)
             col = np.concatenate([col, np.full(n - len(col), None, dtype=object)])
         cols.append(col)
-    lines = [", ".join(["t(s)"] + [f"{nm}:V" for nm in nodes])]
+    lines = [header]
     for k in range(n):
         lines.append(", ".join(c[k] for c in cols if c[k] is not None))
     return "\n".join(lines)
@@ -176,7 +186,9 @@ def js_ordered_items(d: dict):
 
 
 def _to_precision6_array(x: np.ndarray) -> np.ndarray:
-    """Number.prototype.toPrecision(6) for a whole array (object array of str)."""
+    """Number.prototype.toPrecision(6) for a whole array (object array of str).  printf("%.5e") is correctly rounded
+    but breaks exact ties to even where ECMA-262 takes the larger digit string (100000.5 -> "100001"): candidates
+    within 1e-5 of a rounding boundary are redone exactly."""
     x = np.asarray(x, dtype=np.float64)
     out = np.empty(x.shape, dtype=object)
     finite = np.isfinite(x)
@@ -200,21 +212,35 @@ def _to_precision6_array(x: np.ndarray) -> np.ndarray:
             sel = ~big & (np.maximum(0, 5 - e) == dec)
             if sel.any():
                 res[sel] = np.char.mod(f"%.{dec}f", v[sel])
+        with np.errstate(over="ignore", invalid="ignore"):
+            scaled = np.abs(v).astype(np.longdouble) * np.power(np.longdouble(10), (5 - e).astype(np.longdouble))
+            frac = scaled - np.floor(scaled)
+        for i in np.nonzero(~(np.abs(frac - 0.5) > 1e-5))[0]:  # near a boundary (or not computable): exact route
+            res[i] = _to_precision6(float(v[i]))
         out[nz] = res
     return out
 
 
 def _to_precision6(x: float) -> str:
-    """Number.prototype.toPrecision(6)."""
+    """Number.prototype.toPrecision(6), exact: round half UP on the binary value (ECMA-262 picks the larger n)."""
+    import decimal
     if x != x:
         return "NaN"
     if x in (float("inf"), float("-inf")):
         return "Infinity" if x > 0 else "-Infinity"
     if x == 0:
         return "0.00000"
-    s = f"{x:.5e}"
-    mant, exp = s.split("e")
-    e = int(exp)
+    d = decimal.Decimal(abs(x))  # exact
+    e = d.adjusted()
+    with decimal.localcontext() as ctx:
+        ctx.prec = 800
+        n = int((d.scaleb(5 - e)).to_integral_value(rounding=decimal.ROUND_HALF_UP))
+    if n == 1000000:
+        n, e = 100000, e + 1
+    digits = str(n)
+    sign = "-" if x < 0 else ""
     if e < -6 or e >= 6:
-        return f"{mant}e{'+' if e >= 0 else '-'}{abs(e)}"
-    return f"{x:.{max(0, 5 - e)}f}"
+        return f"{sign}{digits[0]}.{digits[1:]}e{'+' if e >= 0 else '-'}{abs(e)}"
+    if e >= 0:
+        return sign + digits[: e + 1] + ("." + digits[e + 1:] if e < 5 else "")
+    return sign + "0." + "0" * (-e - 1) + digits

@@ -159,3 +159,26 @@ def test_vgraph_formatter_matches_reference(name, oracle_backend):
     eec = eecEngineTranToVGraphs({"time_s": [0, 1e-3, 2.5e-3], "voltages": {"out": [0, 1.5, 3.25], "2": [1, 2, 3]}}, ckt, "exp_2")
     assert json.loads(json.dumps(eec)) == g["eec"] and [e["name"] for e in eec] == [e["name"] for e in g["eec"]]
     assert spiceyTranToVGraphs(None, ckt, "x") == []
+
+
+def test_to_precision6_matches_js_engine():
+    """Number.prototype.toPrecision(6) of V8 (tests/golden/toprecision6.json: 9 701 values incl. exact ties, the
+    1e-7 / 1e6 notation switches, denormals, +-0, NaN, Infinity): the scalar and vectorised Python formatters and the
+    native one of libspicey_hip.so (host code; loads without a GPU) all reproduce it character for character."""
+    from spicey_amd.simulate import _to_precision6, _to_precision6_array
+    g = load_golden("toprecision6")
+    vals = np.array([float(v) for v in g["values"]])
+    assert [_to_precision6(float(v)) for v in vals] == g["strings"]
+    assert list(_to_precision6_array(vals)) == g["strings"]
+    from spicey_amd.lib import format_tran_native, to_precision6_native
+    assert [to_precision6_native(v) for v in vals] == g["strings"]
+    # and the table formatter (threads, column selection, header) against the line-by-line composition
+    n = 1500
+    t = vals[:n]
+    mat = np.stack([vals[100:100 + n], vals[2000:2000 + n], vals[4000:4000 + n]], axis=1)
+    text = format_tran_native(t, mat, [2, 0], "t(s), b:V, a:V")
+    want = ["t(s), b:V, a:V"] + [", ".join([g["strings"][k], g["strings"][4000 + k], g["strings"][100 + k]]) for k in range(n)]
+    assert text == "\n".join(want)
+    big = np.tile(mat, (200, 1))  # 300 000 x 3: the multi-threaded path
+    tb = np.tile(t, 200)
+    assert format_tran_native(tb, big, [0, 1, 2], "h").split("\n")[1:] == [", ".join([g["strings"][k % n], g["strings"][100 + k % n], g["strings"][2000 + k % n], g["strings"][4000 + k % n]]) for k in range(len(tb))]

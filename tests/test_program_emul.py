@@ -221,7 +221,7 @@ def test_abi_library_exports_header_symbols():
         import __graft_entry__
         __graft_entry__.build()
     hdr = open(os.path.join(REPO, "include", "spicey_hip.h")).read()
-    declared = set(re.findall(r"\b(spicey_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(spicey_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(lib.EXPORTS)
     L = ctypes.CDLL(lib.LIB_PATH)
     for sym in declared:
