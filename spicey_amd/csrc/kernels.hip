@@ -146,17 +146,21 @@ struct GpuExecV2 {
   // tail: wave 0 runs `nlev` dependent levels back to back.  LDS operations of one wave execute in order, so a
   // level's ds_writes are seen by the next level's ds_reads without any workgroup barrier; the fences only stop
   // the compiler from moving or caching LDS accesses across levels.
-  template <class F>
-  __device__ __forceinline__ void tail_phase(int tag, int nlev, F f) {
+  template <class L, class F>
+  __device__ __forceinline__ void tail_phase(int tag, int nlev, L load, F f) {
     long long t0 = 0;
     if (prof && threadIdx.x == 0) t0 = clock64();
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
     if (tid < 64) {
+      uint32_t cur[4], nxt[4] = {0u, 0u, 0u, 0u};
+      load(tid, 0, cur);
       for (int l = 0; l < nlev; l++) {
-        f(tid, l);
+        if (l + 1 < nlev) load(tid, l + 1, nxt);  // records are read-only: safe to fetch ahead of level l's writes
+        f(tid, l, cur);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2]; cur[3] = nxt[3];
       }
     }
     __syncthreads();

@@ -1079,11 +1079,16 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
         });
       }
       if (k_begin > u_end) {
-        ex.tail_phase(SPICEY_PH_U0 + 31, k_begin - u_end, [&](int tid, int lvl) {
-          const uint32_t *r = c.tail + ((size_t)lvl * 64 + tid) * 4;
-          if (u_end + lvl < nL) spicey_exec_rec16<K, false>(c, P.ovf16, r[0], r[1], r[2], r[3]);
-          else spicey_exec_rec16<K, true>(c, P.ovf16, r[0], r[1], r[2], r[3]);
-        });
+        // the record of level l + 1 is fetched (LDS) while level l executes: one round trip less on the serial chain
+        ex.tail_phase(SPICEY_PH_U0 + 31, k_begin - u_end,
+                      [&](int tid, int lvl, uint32_t *r) {
+                        const uint32_t *q = c.tail + ((size_t)lvl * 64 + tid) * 4;
+                        r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3];
+                      },
+                      [&](int, int lvl, const uint32_t *r) {
+                        if (u_end + lvl < nL) spicey_exec_rec16<K, false>(c, P.ovf16, r[0], r[1], r[2], r[3]);
+                        else spicey_exec_rec16<K, true>(c, P.ovf16, r[0], r[1], r[2], r[3]);
+                      });
       }
       for (int p = k_begin; p < 2 * nL - 1; p++) {
         const int l = 2 * nL - 1 - p;

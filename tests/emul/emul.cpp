@@ -27,13 +27,14 @@ struct SeqExec {
     return (*static_cast<std::vector<Regs> *>(rr))[tid];
   }
   // one wave, `nlev` dependent levels in lockstep: every lane finishes level l before any lane starts l + 1
-  template <class F>
-  void tail_phase(int, int nlev, F f) {
+  template <class L, class F>
+  void tail_phase(int, int nlev, L load, F f) {
     for (int l = 0; l < nlev; l++) {
+      uint32_t r[4];
       if (!reverse)
-        for (int t = 0; t < 64; t++) f(t, l);
+        for (int t = 0; t < 64; t++) { load(t, l, r); f(t, l, r); }
       else
-        for (int t = 63; t >= 0; t--) f(t, l);
+        for (int t = 63; t >= 0; t--) { load(t, l, r); f(t, l, r); }
     }
   }
   template <class F>
