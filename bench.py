@@ -193,6 +193,7 @@ def main():
                 "instances_total": B * n_gpus, "parallelism": f"instance-sharded x{n_gpus}, no data-path collective",
                 "inst_per_workgroup": info["inst_per_wg"], "threads": info["threads"], "lds_bytes": info["lds_bytes"],
                 "nnz_a": info["nnz_a"], "nnz_lu": info["nnz_lu"], "levels": info["n_levels"],
+                "factor_reuse": info.get("factor_reuse", 0),  # 1 = linear circuit: "solve-only" rate, factors of step 0 reused
                 "interpreter": info["interpreter"], "geometry": info["geometry"], "tail_levels": info["tail_levels"], "resident_tasks": info["resident_tasks"], "streamed_tasks": info["streamed_tasks"],
             },
             "roofline": {

@@ -89,7 +89,8 @@ typedef struct SpiceyOptions {
   int32_t interpreter;   /* 0 auto; 1 = v1 (32-bit sliced task lists from L2); 2 = v2 (register-resident 16-bit records) */
   int32_t geometry;      /* v2 only. 0 auto; 1 = latency: one workgroup per CU, whole program in registers;
                             2 = throughput: two 512-thread workgroups per CU (<= 128 VGPRs, wide levels streamed) */
-  int32_t debug;         /* diagnostics: bit 0 = no tail merge; bits 8.. = extra empty phases per solve */
+  int32_t debug;         /* diagnostics: bit 0 = no tail merge; bit 1 = refactor every step even for linear circuits;
+                            bits 8.. = extra empty phases per solve */
   int32_t wgs_per_inst;  /* global-workspace path: workgroups (CUs) cooperating on one instance; 0 auto, 1 = none */
 } SpiceyOptions;
 
@@ -113,6 +114,8 @@ typedef struct SpiceyInfo {
   int64_t streamed_tasks;   /* v2: tasks still fetched from L2 every step */
   int64_t program_bytes;            /* device-side schedule ("program") size */
   int64_t algorithmic_bytes_solve;  /* SURVEY.md §8(d) formula */
+  int32_t factor_reuse;     /* 1: no diodes / switches -> the factors of step 0 are reused, later steps solve only */
+  int32_t reserved0;
 } SpiceyInfo;
 
 typedef struct SpiceyHandle SpiceyHandle;

@@ -46,7 +46,7 @@ class SpiceyInfo(C.Structure):
                 ("n_out", C.c_int32), ("n_workgroups", C.c_int32), ("interpreter", C.c_int32), ("geometry", C.c_int32),
                 ("tail_levels", C.c_int32), ("wgs_per_inst", C.c_int32), ("resident_slots", C.c_int32),
                 ("resident_tasks", C.c_int64), ("streamed_tasks", C.c_int64), ("program_bytes", C.c_int64),
-                ("algorithmic_bytes_solve", C.c_int64)]
+                ("algorithmic_bytes_solve", C.c_int64), ("factor_reuse", C.c_int32), ("reserved0", C.c_int32)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}

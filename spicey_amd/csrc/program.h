@@ -120,6 +120,7 @@ struct SpiceyProg {
 // phase (res_phase[wave][slot], -1 = unused) so the per-phase dispatch is wave-uniform.  Phases that
 // did not fit stay streamed: st_first/st_cnt index rec16.
 struct SpiceyResident {
+  const uint32_t *st_rhs;  // [2L] leading right-hand-side tasks of a streamed factor phase (the only ones a reused factorisation runs)
   const uint32_t *res;        // [RMAX][T][4]
   const int32_t *res_phase;   // [T/64][RMAX]
   const uint32_t *st_first;   // [2 nLevels]
@@ -138,6 +139,7 @@ struct SpiceyRun {
   int32_t n_inst;
   int32_t want_currents;
   int32_t debug_empty_phases;  // diagnostics: extra empty barrier phases per solve (0 in production)
+  int32_t no_reuse;            // diagnostics: refactor every step even when the matrix cannot change (linear circuits)
   int64_t steps;
   double dt;
   // parameters

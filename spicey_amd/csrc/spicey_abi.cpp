@@ -294,6 +294,7 @@ extern "C" int32_t spicey_get_info(SpiceyHandle *h, SpiceyInfo *info) {
   info->streamed_tasks = h->hres.streamed_tasks;
   info->program_bytes = (int64_t)h->hp.blob.size();
   info->algorithmic_bytes_solve = h->algo_bytes;
+  info->factor_reuse = (h->hp.hdr.nD == 0 && h->hp.hdr.nS == 0 && h->hp.hdr.nDynEnt == 0 && !((h->opt.debug >> 1) & 1)) ? 1 : 0;
   return SPICEY_OK;
 }
 
@@ -311,6 +312,7 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   R.n_inst = h->n_inst;
   R.want_currents = d_out_i != nullptr;
   R.debug_empty_phases = h->opt.debug >> 8;
+  R.no_reuse = (h->opt.debug >> 1) & 1;
   R.steps = steps;
   R.dt = dt;
   R.R_val = h->d_R; R.C_val = h->d_C; R.L_val = h->d_L;

@@ -664,7 +664,7 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
   hp.bk_d.assign(diag.begin(), diag.end());  // [n]: entry id of every pivot's (reciprocal) diagonal
 
   // ---- 5c'. compact 16-bit records of the same tasks, phases in execution order -------------------
-  hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear();
+  hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear(); hp.ph_rhs.clear();
   hp.hdr.has16 = (nLU + n) < 65535 ? 1 : 0;  // 0xFFFF = ground in the packed terminal words
   if (hp.hdr.has16) {
     auto emit_u = [&](uint32_t tgt, bool recip, const std::vector<uint32_t> &tr) {  // tr = (l,d,u)*
@@ -721,11 +721,17 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
         uts.push_back({t, recip, std::move(tr)});
         i = j;
       }
-      // same (recip, count) next to each other: the 64-lane chunks then take one code path
-      std::stable_sort(uts.begin(), uts.end(), [](const UT &x, const UT &y) {
+      // right-hand-side tasks first (a linear circuit's reused factorisation runs only those), then the same
+      // (recip, count) next to each other: the 64-lane chunks then take one code path
+      std::stable_sort(uts.begin(), uts.end(), [&](const UT &x, const UT &y) {
+        const bool xr = (int)x.t >= nLU, yr = (int)y.t >= nLU;
+        if (xr != yr) return xr;
         if (x.recip != y.recip) return x.recip > y.recip;
         return x.tr.size() > y.tr.size();
       });
+      uint32_t nrhs = 0;
+      for (auto &u : uts) nrhs += (int)u.t >= nLU ? 1u : 0u;
+      hp.ph_rhs.push_back(nrhs);
       for (auto &u : uts) emit_u(u.t, u.recip, u.tr);
       hp.ph_cnt.push_back((uint32_t)(hp.rec16.size() / 4) - hp.ph_first.back());
     }
@@ -743,7 +749,7 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
     }
     if (too_long || hp.ovf16.size() >= (size_t)1 << 31) {  // count field is 8 bits: such circuits use the 32-bit path
       hp.hdr.has16 = 0;
-      hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear();
+      hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear(); hp.ph_rhs.clear();
     }
   }
   hp.hdr.nRec16 = (int32_t)(hp.rec16.size() / 4);
@@ -892,6 +898,7 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
   out.res_phase.assign((size_t)nWaves * rmax, -1);
   out.st_first.assign(std::max(nPh, 1), 0u);
   out.st_cnt.assign(std::max(nPh, 1), 0u);
+  out.st_rhs.assign(std::max(nPh, 1), 0u);
   if (hp.hdr.has16 && nPh <= 254 && max_tail > 1) {
     // tail: longest run of <= 64-task phases around the factor -> backward turn (phase nLevels-1 | nLevels)
     const int nL = hp.hdr.nLevels;
@@ -924,6 +931,7 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
       if (!fits) {  // stays streamed
         out.st_first[p] = hp.ph_first[p];
         out.st_cnt[p] = hp.ph_cnt[p];
+        out.st_rhs[p] = p < (int)hp.ph_rhs.size() ? hp.ph_rhs[p] : hp.ph_cnt[p];
         out.streamed_tasks += cnt;
         continue;
       }
@@ -949,7 +957,10 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
       }
     }
   } else if (hp.hdr.has16) {
-    for (int p = 0; p < nPh; p++) { out.st_first[p] = hp.ph_first[p]; out.st_cnt[p] = hp.ph_cnt[p]; out.streamed_tasks += hp.ph_cnt[p]; }
+    for (int p = 0; p < nPh; p++) {
+      out.st_first[p] = hp.ph_first[p]; out.st_cnt[p] = hp.ph_cnt[p]; out.streamed_tasks += hp.ph_cnt[p];
+      out.st_rhs[p] = p < (int)hp.ph_rhs.size() ? hp.ph_rhs[p] : hp.ph_cnt[p];
+    }
   }
   out.pack();
 }
@@ -961,6 +972,7 @@ void HostResident::pack() {
   add_section(blob, offsets, res_phase);
   add_section(blob, offsets, st_first);
   add_section(blob, offsets, st_cnt);
+  add_section(blob, offsets, st_rhs);
 }
 
 SpiceyResident HostResident::bind(const void *base) const {
@@ -970,6 +982,7 @@ SpiceyResident HostResident::bind(const void *base) const {
   r.res_phase = (const int32_t *)(b + offsets[1]);
   r.st_first = (const uint32_t *)(b + offsets[2]);
   r.st_cnt = (const uint32_t *)(b + offsets[3]);
+  r.st_rhs = (const uint32_t *)(b + offsets[4]);
   r.rmax = rmax;
   r.T = T;
   r.tail_first = tail_first;

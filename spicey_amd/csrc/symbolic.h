@@ -28,6 +28,7 @@ struct HostProgram {
   std::vector<uint32_t> bk_lvl_slice, bk_x, bk_d, bk_cnt, bk_pairs;
   std::vector<SpiceySlice> bk_slice;
   std::vector<uint32_t> rec16, ph_first, ph_cnt;  // compact records (has16)
+  std::vector<uint32_t> ph_rhs;  // per factor phase: its leading right-hand-side tasks (host only)
   std::vector<uint16_t> ovf16;
   std::vector<uint32_t> ent_dd, dynx_ent, dynx_ptr, dynx_idx, row_desc, rowx, R_ab, C_ab, L_ab, D_ab;
   std::vector<int32_t> R_a, R_b, C_a, C_b, L_a, L_b, S_a, S_b, S_cp, S_cn, D_a, D_b, V_x, out_x;
@@ -48,7 +49,7 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
 // Resident (register) layout of the compact records for a workgroup of T threads with `rmax` slots per
 // thread.  Blob sections: res[rmax][T][4] u32, res_phase[T/64][rmax] i32, st_first[2L] u32, st_cnt[2L] u32.
 struct HostResident {
-  std::vector<uint32_t> res, st_first, st_cnt;
+  std::vector<uint32_t> res, st_first, st_cnt, st_rhs;
   std::vector<int32_t> res_phase;
   int rmax = 0, T = 0, tail_first = 0, tail_n = 0;
   int64_t resident_tasks = 0, streamed_tasks = 0;

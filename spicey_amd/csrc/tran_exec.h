@@ -271,7 +271,7 @@ struct TranPhases {
   }
 
   // ---- U_l: Schur updates of one elimination-tree level ----------------------------------------
-  SPICEY_HD void u_level(int tid, int l) const {
+  SPICEY_HD void u_level(int tid, int l, bool reuse = false) const {
     const int nw = T >> 6, w = tid >> 6, lane = tid & 63;
     for (uint32_t s = P.lvl_slice[l] + w; s < P.lvl_slice[l + 1]; s += nw) {
       const uint32_t t = s * 64 + lane;
@@ -280,6 +280,7 @@ struct TranPhases {
       const uint32_t cnt = P.upd_cnt[t];
       const uint32_t off = P.upd_slice[s].off + lane;
       const uint32_t ti = SPICEY_IDX(tgt);
+      if (reuse && ti < (uint32_t)P.nLU) continue;  // reused factorisation: right-hand-side column only
       double acc[K];
       for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)ti * K + k];
       uint32_t j = 0;
@@ -387,7 +388,7 @@ struct TranPhases {
   }
 
   // ---- Z: record, update state, evaluate the next step's companions ----------------------------
-  SPICEY_HD void z_record(int tid, int64_t step) const {
+  SPICEY_HD void z_record(int tid, int64_t step, bool keep_factors = false) const {
     const bool last = step == R.steps;
     const int oL = P.nC, oV = P.nC + P.nL, oD = P.nC + P.nL + P.nV;
     const int cR = 0, cC = P.nR, cL = P.nR + P.nC, cV = cL + P.nL, cS = cV + P.nV, cD = cS + P.nS;
@@ -444,7 +445,7 @@ struct TranPhases {
         if (last) R.D_vdprev[in * P.nD + i] = vd;
       }
     }
-    static_copy(tid);
+    if (!keep_factors) static_copy(tid);  // a linear circuit keeps the factors of step 0 in W
   }
 };
 
@@ -486,10 +487,14 @@ struct ResRegs {
 // are 0, a valid address — and the unused products are masked by selects: one LDS round trip per task instead of
 // one per product (the dependent ds_read -> wait -> fma chains dominated the small phases).
 template <int K, bool KTASK>
-SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
+                                 uint32_t keep_from = 0u) {
   const uint32_t meta = w0 >> 16;
   if (!(meta & (SPICEY_R16_VALID << 8))) return;
   const uint32_t tgt = w0 & 0xffffu, cnt = meta & 0xffu;
+  // a reused factorisation (linear circuit, step > 0) runs only the right-hand-side column of the factor tasks:
+  // keep_from = nLU then, 0 otherwise
+  if (!KTASK && tgt < keep_from) return;
   double acc[K];
   if (KTASK) {
     const uint32_t d = w1 & 0xffffu;
@@ -562,7 +567,8 @@ SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_
 
 template <int K, int RMAX, int NSV, int NEL, bool KTASK>
 SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, const WgCtx<K> &c, ResRegs<K, RMAX, NSV, NEL> &rr, int tid,
-                               int T, int p, bool streamed) {
+                               int T, int p, bool streamed, bool reuse = false) {
+  const uint32_t keep_from = (!KTASK && reuse) ? (uint32_t)P.nLU : 0u;
   if (RMAX <= 8) {
     // few slots: a static compare chain (scalar compares on the wave-uniform phase bytes).  Measured faster than
     // both indexed register access and a binary decision tree on a slot cursor (11.8 vs 16.0 / 15.2 us per step).
@@ -574,7 +580,7 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
       if (sp == p) {
         uint32_t w0 = rr.w0[s], w1 = rr.w1[s], w2 = rr.w2[s], w3 = rr.w3[s];
         SPICEY_OPAQUE(w0); SPICEY_OPAQUE(w1); SPICEY_OPAQUE(w2); SPICEY_OPAQUE(w3);
-        spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3);
+        spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3, keep_from);
       }
     }
   } else {
@@ -587,13 +593,13 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
       if (sp != p) break;
       uint32_t w0 = rr.w0[q], w1 = rr.w1[q], w2 = rr.w2[q], w3 = rr.w3[q];
       SPICEY_OPAQUE(w0); SPICEY_OPAQUE(w1); SPICEY_OPAQUE(w2); SPICEY_OPAQUE(w3);
-      spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3);
+      spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3, keep_from);
       q++;
     }
     rr.cursor = q;
   }
   if (!streamed) return;
-  const uint32_t sc = Q.st_cnt[p];
+  const uint32_t sc = (!KTASK && reuse) ? Q.st_rhs[p] : Q.st_cnt[p];  // right-hand-side tasks lead every factor phase
   if (sc) {
     // streamed phase (did not fit the resident slots): double-buffered — the next record's L2 fetch is in flight
     // while the current task executes.  (Fetching 4 records up front was measured slower: +16 live VGPRs pushed
@@ -608,7 +614,7 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
         const bool more = jn < sc;
         const uint32_t *rn = base + (size_t)(more ? jn : j) * 4;
         const uint32_t n0 = rn[0], n1 = rn[1], n2 = rn[2], n3 = rn[3];
-        spicey_exec_rec16<K, KTASK>(c, P.ovf16, c0, c1, c2, c3);
+        spicey_exec_rec16<K, KTASK>(c, P.ovf16, c0, c1, c2, c3, keep_from);
         if (!more) break;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         j = jn;
@@ -750,10 +756,14 @@ struct TranPhases2 {
   }
 
   // ---- B: matrix = static + dynamic stamps; right-hand side -----------------------------------------
-  SPICEY_HD void b_stamp(int tid, Regs &rr) const {
+  SPICEY_HD void b_stamp(int tid, Regs &rr, bool reuse = false) const {
     SPICEY_MARK(c, 15);
     if (tid == 0) c.flags[0] = 0;
     rr.cursor = 0;  // a new solve walks the resident slots from the start
+    if (!reuse) stamp_matrix(tid, rr);  // a linear circuit keeps the factors of step 0 in W
+    rhs_rows(tid, rr);
+  }
+  SPICEY_HD void stamp_matrix(int tid, Regs &rr) const {
     for (int j = 0; j < Regs::NDD; j++) {
       const uint32_t e = (uint32_t)(tid + j * T);
       uint32_t dd = rr.dd[j];
@@ -807,6 +817,8 @@ struct TranPhases2 {
         c.W[(size_t)e * K + k] = v;
       }
     }
+  }
+  SPICEY_HD void rhs_rows(int tid, Regs &rr) const {
     SPICEY_MARK(c, 9);
     for (int j = 0; j < NEL; j++) {
       uint32_t d0 = rr.rhs[j][0], d1 = rr.rhs[j][1];
@@ -1058,6 +1070,10 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
   const int u_end = Q.tail_n > 0 ? Q.tail_first : nL;
   const int k_begin = Q.tail_n > 0 ? Q.tail_first + Q.tail_n : nL;
   const bool z_pre = K == 1 && k_begin < 2 * nL;  // Z's parameter fetch rides on the last backward phase
+  // No diodes and no switches: the matrix of every step is the matrix of step 0 (dt is fixed within a run), so its
+  // factors stay in W and later steps run the right-hand-side column only.  Same operands, same order: the results
+  // are bit-identical to refactoring (SURVEY.md §8(d) "solve-only" rate; the reference itself never reuses).
+  const bool linear = P.nD == 0 && P.nS == 0 && P.nDynEnt == 0 && !R.no_reuse;
   for (int64_t step = 0; step <= R.steps && code == 0; step++) {
     int iter = 0;
     for (;;) {
@@ -1066,7 +1082,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
         // LDS last; Z moves them into place
         double sn = K == 1 ? p2.z_src_fetch(tid, step) : 0.0;
         SPICEY_SCHED_FENCE;
-        p2.b_stamp(tid, ex.template regs<Regs>(tid));
+        p2.b_stamp(tid, ex.template regs<Regs>(tid), linear && step > 0);
         SPICEY_SCHED_FENCE;
         if (K == 1) p2.z_src_park(tid, sn);
       });
@@ -1075,7 +1091,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
       for (int p = 0; p < u_end; p++) {
         if (p < 64 ? !((active >> p) & 1) : P.ph_cnt[p] == 0) continue;
         ex.phase(SPICEY_PH_U0 + (p < 30 ? p : 30), [&](int tid) {
-          spicey_uk_phase<K, RMAX, NSV, NEL, false>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
+          spicey_uk_phase<K, RMAX, NSV, NEL, false>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true, linear && step > 0);
         });
       }
       if (k_begin > u_end) {
@@ -1086,7 +1102,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
                         r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3];
                       },
                       [&](int, int lvl, const uint32_t *r) {
-                        if (u_end + lvl < nL) spicey_exec_rec16<K, false>(c, P.ovf16, r[0], r[1], r[2], r[3]);
+                        if (u_end + lvl < nL) spicey_exec_rec16<K, false>(c, P.ovf16, r[0], r[1], r[2], r[3], (linear && step > 0) ? (uint32_t)P.nLU : 0u);
                         else spicey_exec_rec16<K, true>(c, P.ovf16, r[0], r[1], r[2], r[3]);
                       });
       }
@@ -1156,6 +1172,7 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
   int64_t err_step = 0;
   int32_t err_iter = 0;
   if (c.flags[1]) { code = 1; }
+  const bool linear = P.nD == 0 && P.nS == 0 && P.nDynEnt == 0 && !R.no_reuse;  // see spicey_tran_run_v2
   for (int64_t step = 0; step <= R.steps && code == 0; step++) {
     if (ex.failed()) { code = 3; err_step = step; break; }  // a cross-workgroup barrier timed out (group mode only)
     int iter = 0;
@@ -1163,7 +1180,7 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
       ex.phase(SPICEY_PH_B, [&](int tid) { ph.b_stamp(tid); });
       for (int l = 0; l < P.nLevels; l++) {
         if (P.lvl_slice[l] == P.lvl_slice[l + 1]) continue;
-        ex.phase(SPICEY_PH_U0 + (l < 31 ? l : 31), [&](int tid) { ph.u_level(tid, l); });
+        ex.phase(SPICEY_PH_U0 + (l < 31 ? l : 31), [&](int tid) { ph.u_level(tid, l, linear && step > 0); });
       }
       for (int l = P.nLevels - 1; l >= 0; l--) {
         if (P.bk_lvl_slice[l] == P.bk_lvl_slice[l + 1]) continue;
@@ -1188,7 +1205,7 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
       if (tid == 0 && R.iters)
         for (int k = 0; k < K; k++)
           if (c.valid[k]) R.iters[(size_t)c.inst[k] * (size_t)(R.steps + 1) + (size_t)step] = iter + 1;
-      ph.z_record(tid, step);
+      ph.z_record(tid, step, linear);
     });
   }
   ex.phase(SPICEY_PH_PRO, [&](int tid) {

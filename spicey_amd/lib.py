@@ -89,7 +89,8 @@ class Handle:
     """Owns one SpiceyHandle (one topology, n_inst instances, one device)."""
 
     def __init__(self, flat: abi.FlatCircuit, device: int = 0, threads: int = 0, inst_per_wg: int = 0,
-                 force_global: bool = False, profile: bool = False, interpreter: int = 0, geometry: int = 0, no_tail: bool = False, debug_empty_phases: int = 0, wgs_per_inst: int = 0):
+                 force_global: bool = False, profile: bool = False, interpreter: int = 0, geometry: int = 0, no_tail: bool = False, debug_empty_phases: int = 0, wgs_per_inst: int = 0,
+                 no_reuse: bool = False):
         self.L = load()
         self.flat = flat
         opt = abi.SpiceyOptions()
@@ -98,7 +99,7 @@ class Handle:
         opt.interpreter = int(interpreter)
         opt.geometry = int(geometry)
         opt.wgs_per_inst = int(wgs_per_inst)
-        opt.debug = (1 if no_tail else 0) | (int(debug_empty_phases) << 8)
+        opt.debug = (1 if no_tail else 0) | (2 if no_reuse else 0) | (int(debug_empty_phases) << 8)
         d = flat.desc()
         hp = C.c_void_p()
         rc = self.L.spicey_create(C.byref(d), C.byref(opt), C.byref(hp))
@@ -252,9 +253,9 @@ class HipBackend:
     """Backend interface used by spicey_amd.simulate: one handle per call (the reference API is stateless)."""
 
     def __init__(self, device: int = 0, threads: int = 0, inst_per_wg: int = 0, force_global: bool = False, interpreter: int = 0,
-                 geometry: int = 0, wgs_per_inst: int = 0):
+                 geometry: int = 0, wgs_per_inst: int = 0, no_reuse: bool = False):
         self.kw = dict(device=device, threads=threads, inst_per_wg=inst_per_wg, force_global=force_global, interpreter=interpreter,
-                       geometry=geometry, wgs_per_inst=wgs_per_inst)
+                       geometry=geometry, wgs_per_inst=wgs_per_inst, no_reuse=no_reuse)
         self.info: Optional[dict] = None
 
     def run(self, flat: abi.FlatCircuit, steps: int, dt: float, src: np.ndarray, want_currents: bool = True,

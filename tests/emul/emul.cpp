@@ -109,6 +109,7 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
   const int ni = d->n_inst;
   SpiceyRun R{};
   R.n_inst = ni; R.want_currents = out_i != nullptr; R.steps = steps; R.dt = dt;
+  R.no_reuse = (reverse >> 1) & 1;  // bit 1 of `reverse`: refactor every step (to check the reuse path against)
   R.R_val = d->R_val; R.C_val = d->C_val; R.L_val = d->L_val;
   R.S_ron = d->S_ron; R.S_roff = d->S_roff; R.S_von = d->S_von; R.S_voff = d->S_voff;
   R.D_is = d->D_is; R.D_n = d->D_n;
@@ -124,9 +125,9 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
   if (T <= 0 || (T & 63)) return SPICEY_ERR_BAD_DESC;
   if (rmax > 16 || (rmax >= 0 && (!P.has16 || K > 2))) return SPICEY_ERR_BAD_DESC;  // v2 supports K <= 2
   switch (K) {
-    case 1: run_groups<1>(hp, P, R, T, reverse != 0, rmax); break;
-    case 2: run_groups<2>(hp, P, R, T, reverse != 0, rmax); break;
-    case 4: run_groups<4>(hp, P, R, T, reverse != 0, rmax); break;
+    case 1: run_groups<1>(hp, P, R, T, (reverse & 1) != 0, rmax); break;
+    case 2: run_groups<2>(hp, P, R, T, (reverse & 1) != 0, rmax); break;
+    case 4: run_groups<4>(hp, P, R, T, (reverse & 1) != 0, rmax); break;
     default: return SPICEY_ERR_BAD_DESC;
   }
   int64_t tot = 0;

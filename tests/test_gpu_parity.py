@@ -362,3 +362,23 @@ def test_random_circuits_on_gpu(oracle_backend):
         ran += 1
         multi += int(ref["iters"].max() > 1)
     assert ran == 191 and multi > 20
+
+
+def test_linear_circuits_reuse_factorisation_on_gpu(oracle_backend):
+    """rc_ladder(1000) (BASELINE configs 1 / 3: linear): reusing the factors of step 0 is bit-identical to refactoring
+    every step in every geometry, and within tolerance of the oracle; the info block says which mode ran."""
+    from spicey_amd.lib import HipBackend
+    flat, dt, steps, src = synth.chain_batch("rc_ladder", 1000, [1, 2], tran=".tran 1e-6 6e-5")
+    ref = oracle_backend.run(flat, steps, dt, src)
+    for kw in (dict(), dict(geometry=2), dict(interpreter=1), dict(force_global=True), dict(threads=256, inst_per_wg=2)):
+        a_be, b_be = HipBackend(**kw), HipBackend(no_reuse=True, **kw)
+        a = a_be.run(flat, steps, dt, src)
+        b = b_be.run(flat, steps, dt, src)
+        assert a["status"] == b["status"] == 0
+        assert a_be.info["factor_reuse"] == 1 and b_be.info["factor_reuse"] == 0
+        assert np.array_equal(a["out_v"], b["out_v"]) and np.array_equal(a["out_i"], b["out_i"]), kw
+        assert tol_ratio(a["out_v"], ref["out_v"]).max() <= 1.0 and tol_ratio(a["out_i"], ref["out_i"]).max() <= 1.0
+    f2, dt2, st2, src2 = synth.chain_batch("diode_chain", 40, [1], tran=".tran 1e-6 3e-5")
+    nl = HipBackend()
+    nl.run(f2, st2, dt2, src2)
+    assert nl.info["factor_reuse"] == 0

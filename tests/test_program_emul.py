@@ -378,3 +378,34 @@ def test_random_circuit_outliers_arbitrated_in_extended_precision(oracle_backend
         assert e_got <= max(1.0, 4.0 * e_ref) or e_got <= 5.0, (seed, e_ref, e_got)
     assert seen[2610][0] > 10 * 1.0 and seen[2610][1] < seen[2610][0]  # here the reference is the less accurate one
     assert seen[2703][1] <= 1.0  # the chattering switch: within budget while the iteration converges
+
+
+@pytest.mark.parametrize("name", ["ladder20", "lc_tank", "transient01", "two_probes", "float_cap", "units_title"])
+def test_linear_circuits_reuse_their_factorisation_bit_identically(name, oracle_backend):
+    """No diodes, no switches: the factors of step 0 stay in the workspace and later steps run the right-hand-side
+    column only.  Same operands in the same order: bit-identical to refactoring every step, in both interpreters."""
+    flat, steps, dt, src = _inputs(name)
+    assert flat.nD == 0 and flat.nS == 0
+    ref = oracle_backend.run(flat, steps, dt, src)
+    for T, rmax in ((64, -1), (64, 2), (128, 16), (256, 0)):
+        a = EmulBackend(1, T, False, rmax).run(flat, steps, dt, src)
+        b = EmulBackend(1, T, False, rmax, no_reuse=True).run(flat, steps, dt, src)
+        assert a["status"] == b["status"] == 0
+        assert np.array_equal(a["out_v"], b["out_v"]) and np.array_equal(a["out_i"], b["out_i"], equal_nan=True)
+        assert ratio(a["out_v"], ref["out_v"]).max() <= 1.0
+    # second run continues from the first (state carried, factorisation redone at the new step 0)
+    two = EmulBackend(1, 64, False, 2)
+    r1 = two.run(flat, steps, dt, src)
+    flat2 = flat.replicate(1)
+    for k in ("C_vprev", "L_iprev"):
+        getattr(flat2, k)[:] = r1["state"][k]
+    r2 = two.run(flat2, steps, dt, src)
+    o1 = oracle_backend.run(flat2, steps, dt, src)
+    assert ratio(r2["out_v"], o1["out_v"]).max() <= 1.0
+
+
+def test_reuse_is_off_for_nonlinear_circuits():
+    flat, steps, dt, src = _inputs("dchain20")
+    a = EmulBackend(1, 64, False, 2).run(flat, steps, dt, src)
+    b = EmulBackend(1, 64, False, 2, no_reuse=True).run(flat, steps, dt, src)
+    assert np.array_equal(a["out_v"], b["out_v"])
