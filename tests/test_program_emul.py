@@ -409,3 +409,56 @@ def test_reuse_is_off_for_nonlinear_circuits():
     a = EmulBackend(1, 64, False, 2).run(flat, steps, dt, src)
     b = EmulBackend(1, 64, False, 2, no_reuse=True).run(flat, steps, dt, src)
     assert np.array_equal(a["out_v"], b["out_v"])
+
+
+def test_descriptor_validation_through_the_c_abi():
+    """spicey_create / spicey_ac_create reject malformed descriptors with SPICEY_ERR_BAD_DESC and a message (the
+    stamping / dimension guards of the reference): checked before any device work, so also on a box
+    without a GPU.  A valid descriptor gets past validation (and then fails with NO_DEVICE here, or succeeds on the GPU
+    box)."""
+    import ctypes as C
+    from spicey_amd import lib
+    L = lib.load()
+    base = abi.flatten(parseNetlist(synth.rc_ladder(6)))
+
+    def create(flat, mutate=None, ac=False):
+        d = flat.desc()
+        if mutate:
+            mutate(d)
+        opt = abi.SpiceyOptions()
+        h = C.c_void_p()
+        f, err, destroy = (L.spicey_ac_create, L.spicey_ac_last_error, L.spicey_ac_destroy) if ac else (L.spicey_create, L.spicey_last_error, L.spicey_destroy)
+        rc = f(C.byref(d), C.byref(opt), C.byref(h))
+        msg = err(None).decode()
+        if rc == abi.OK:
+            destroy(h)
+        return rc, msg
+
+    for ac in (False, True):
+        rc, msg = create(base, ac=ac)
+        assert rc in (abi.OK, abi.ERR_NO_DEVICE), msg
+        rc, msg = create(base, lambda d: setattr(d, "abi_version", 99), ac)
+        assert rc == abi.ERR_BAD_DESC and "abi_version" in msg
+        rc, msg = create(base, lambda d: setattr(d, "n_inst", 0), ac)
+        assert rc == abi.ERR_BAD_DESC
+        rc, msg = create(base, lambda d: setattr(d, "nR", -1), ac)
+        assert rc == abi.ERR_BAD_DESC
+        rc, msg = create(base, lambda d: setattr(d, "R_n1", C.POINTER(C.c_int32)()), ac)
+        assert rc == abi.ERR_BAD_DESC and "null" in msg
+        bad = abi.flatten(parseNetlist(synth.rc_ladder(6)))  # (replicate() shares the topology arrays)
+        bad.R_n1[2] = base.n_nodes + 3
+        rc, msg = create(bad, ac=ac)
+        assert rc == abi.ERR_BAD_DESC and "out of range" in msg
+        bad = abi.flatten(parseNetlist(synth.rc_ladder(6)))
+        bad.C_n2[0] = -2
+        rc, msg = create(bad, ac=ac)
+        assert rc == abi.ERR_BAD_DESC and "out of range" in msg
+    probe = abi.flatten(parseNetlist(synth.rc_ladder(6)))
+    probe.out_nodes = np.array([1, 99], np.int32)
+    rc, msg = create(probe)
+    assert rc == abi.ERR_BAD_DESC and "out_nodes" in msg
+    h = C.c_void_p()
+    assert L.spicey_create(None, None, C.byref(h)) == abi.ERR_BAD_DESC
+    assert L.spicey_create(C.byref(base.desc()), None, None) == abi.ERR_BAD_DESC
+    assert L.spicey_run(None, 1, 1e-6, None, None, None, None) == abi.ERR_BAD_DESC
+    assert L.spicey_ac_run(None, 1, None, None, None, None) == abi.ERR_BAD_DESC
