@@ -124,3 +124,55 @@ def run(flat, steps, dt, src):
         for i in range(flat.nD):
             vdprev[i] = v(x, flat.D_np[i]) - v(x, flat.D_nm[i])
     return out, iters
+
+
+def run_ac(flat, freqs, vph):
+    """Extended-precision dense complex solve of the AC system (simulateAC.ts:25-62 + partial pivoting) per frequency.
+    Returns complex128 [n_freq][n_nodes] (rounded from 80-bit)."""
+    CL = np.clongdouble
+    J = CL(1j)
+    nN, nV = flat.n_nodes, flat.nV
+    n = nN + nV
+    out = np.zeros((len(freqs), nN), np.complex128)
+    for fi, f in enumerate(freqs):
+        A = np.zeros((n, n), CL)
+        b = np.zeros(n, CL)
+
+        def adm(n1, n2, Y):
+            i1, i2 = n1 - 1, n2 - 1
+            if i1 >= 0:
+                A[i1, i1] += Y
+            if i2 >= 0:
+                A[i2, i2] += Y
+            if i1 >= 0 and i2 >= 0:
+                A[i1, i2] -= Y
+                A[i2, i1] -= Y
+
+        w = LD(2 * 3.141592653589793) * LD(f)
+        for i in range(flat.nR):
+            adm(flat.R_n1[i], flat.R_n2[i], CL(LD(1) / LD(flat.R_val[0, i])))
+        for i in range(flat.nC):
+            adm(flat.C_n1[i], flat.C_n2[i], J * CL(w * LD(flat.C_val[0, i])))
+        for i in range(flat.nL):
+            adm(flat.L_n1[i], flat.L_n2[i], CL(1) / (J * CL(w * LD(flat.L_val[0, i]))))
+        for k in range(nV):
+            i1, i2, j = flat.V_n1[k] - 1, flat.V_n2[k] - 1, nN + k
+            if i1 >= 0:
+                A[i1, j] += 1
+                A[j, i1] += 1
+            if i2 >= 0:
+                A[i2, j] -= 1
+                A[j, i2] -= 1
+            b[j] += CL(vph[k])
+        M = np.concatenate([A, b[:, None]], axis=1)
+        for k in range(n):
+            im = k + int(np.argmax(np.abs(M[k:, k])))
+            M[[k, im]] = M[[im, k]]
+            for i in range(k + 1, n):
+                if M[i, k] != 0:
+                    M[i, k:] -= M[i, k] / M[k, k] * M[k, k:]
+        x = np.zeros(n, CL)
+        for i in range(n - 1, -1, -1):
+            x[i] = (M[i, n] - M[i, i + 1:n] @ x[i + 1:]) / M[i, i]
+        out[fi] = np.array(x[:nN], dtype=complex)
+    return out
