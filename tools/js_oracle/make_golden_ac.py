@@ -6,6 +6,9 @@ make_golden.py: erase_types.py --ac writes type-erased twins into a mkdtemp scra
 inside the repo), driver_ac.mjs imports the reference's parseNetlist + simulateAC + formatAcResult from there, and only
 numbers (and the reference's formatted text output) are stored under tests/golden/.
 
+It also writes tests/golden/vgraph_*.json: the reference's spiceyTranToVGraphs / eecEngineTranToVGraphs
+(lib/formatting/formatToVGraph.ts, through driver_vgraph.mjs) on two of the reference's own test netlists.
+
 Usage: python3 tools/js_oracle/make_golden_ac.py [--only NAME ...]
 """
 import argparse
@@ -102,6 +105,16 @@ def main():
             out["nodes"] = out["nodes"][:8] + ["..."]
             json.dump(out, open(os.path.join(GOLD, name + ".json"), "w"))
             print(name, out["ms"], "ms", nf, "freqs", out["sha256_V"])
+        for name in ("two_probes", "switch_vt_vh"):
+            if not want("vgraph_" + name):
+                continue
+            with tempfile.TemporaryDirectory(prefix="spicey_gold_") as td:
+                out = os.path.join(td, "out.json")
+                subprocess.run(NODE + [os.path.join(HERE, "driver_vgraph.mjs"), root, os.path.join(GOLD, "netlists", name + ".cir"), out], check=True)
+                g = json.load(open(out))
+            g["netlist_file"] = f"netlists/{name}.cir"
+            json.dump(g, open(os.path.join(GOLD, f"vgraph_{name}.json"), "w"))
+            print("vgraph_" + name, len(g["graphs"]), "graphs")
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
