@@ -121,7 +121,9 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   SpiceyHandle *h = new SpiceyHandle();
   if (opt) h->opt = *opt;
   std::string err;
+  spicey_symbolic_set_bank_aware(!((h->opt.debug >> 2) & 1));  // diagnostics: bit 2 = plain CSR numbering of the entries
   int32_t rc = spicey_build_program(desc, h->hp, err);
+  spicey_symbolic_set_bank_aware(true);
   if (rc != SPICEY_OK) {
     g_err = err;
     delete h;

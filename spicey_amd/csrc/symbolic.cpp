@@ -15,6 +15,7 @@
 #include "symbolic.h"
 
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <functional>
 #include <numeric>
@@ -326,7 +327,67 @@ int64_t spicey_algorithmic_bytes(const SpiceyDesc *d, int32_t nnzA, int32_t nnzL
          16 * ((int64_t)d->nC + d->nL + d->nD) + 8 * ((int64_t)d->n_nodes + etot);
 }
 
+static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err);
+
+static bool g_bank_aware = true;
+void spicey_symbolic_set_bank_aware(bool on) { g_bank_aware = on; }
+
+// LDS cycles the operand reads of the compact records cost per solve (every half-wave group and operand role: the
+// largest number of distinct addresses on one bank) and the conflict-free minimum (one per group and role).
+void spicey_bank_cost(const HostProgram &hp, int64_t *cycles, int64_t *ideal) {
+  *cycles = 0; *ideal = 0;
+  const int nL = hp.hdr.nLevels;
+  for (int p = 0; p < (int)hp.ph_cnt.size(); p++) {
+    const bool ktask = p >= nL;
+    for (uint32_t g0 = 0; g0 < hp.ph_cnt[p]; g0 += 32) {
+      const uint32_t g1 = std::min(hp.ph_cnt[p], g0 + 32);
+      for (int role = 0; role < 7; role++) {
+        std::vector<std::vector<uint32_t>> bank(32);
+        bool any = false;
+        for (uint32_t t = g0; t < g1; t++) {
+          const uint32_t *r = &hp.rec16[((size_t)hp.ph_first[p] + t) * 4];
+          const uint32_t cnt = (r[0] >> 16) & 0xffu;
+          if (cnt > 2) continue;
+          const uint32_t f[7] = {r[0] & 0xffffu, r[1] & 0xffffu, r[1] >> 16, r[2] & 0xffffu, r[2] >> 16, r[3] & 0xffffu, r[3] >> 16};
+          const int nf = ktask ? (cnt == 0 ? 2 : cnt == 1 ? 4 : 6) : (cnt == 0 ? 1 : cnt == 1 ? 4 : 7);
+          if (role >= nf) continue;
+          auto &b = bank[f[role] & 31];
+          if (std::find(b.begin(), b.end(), f[role]) == b.end()) b.push_back(f[role]);
+          any = true;
+        }
+        if (!any) continue;
+        size_t worst = 1;
+        for (auto &b : bank) worst = std::max(worst, b.size());
+        *cycles += (int64_t)worst;
+        *ideal += 1;
+      }
+    }
+  }
+}
+
+// Two candidate numberings of the L+U entries (see build_program_impl): slot-major ("bank-aware") and plain CSR
+// order.  For programs that run from LDS (16-bit records) both are compiled and the one whose operand reads cost fewer
+// LDS cycles is kept (chains: 2.65 -> 1.88 conflict factor; small meshes are sometimes better off in CSR order).
+// Circuits on the global-workspace path keep the CSR order: LDS banks do not matter there.
 int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err) {
+  hp = HostProgram();
+  const bool want = g_bank_aware;
+  g_bank_aware = false;
+  int32_t rc = build_program_impl(d, hp, err);
+  g_bank_aware = want;
+  if (rc != SPICEY_OK || hp.structurally_singular || !hp.hdr.has16 || !want) return rc;
+  HostProgram alt;
+  std::string err2;
+  if (build_program_impl(d, alt, err2) == SPICEY_OK && alt.hdr.has16) {
+    int64_t c0, i0, c1, i1;
+    spicey_bank_cost(hp, &c0, &i0);
+    spicey_bank_cost(alt, &c1, &i1);
+    if (c1 < c0) hp = std::move(alt);
+  }
+  return rc;
+}
+
+static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err) {
   if (!d) { err = "null descriptor"; return SPICEY_ERR_BAD_DESC; }
   if (d->abi_version != SPICEY_ABI_VERSION) { err = "abi_version mismatch"; return SPICEY_ERR_BAD_DESC; }
   const int nN = d->n_nodes, nR = d->nR, nC = d->nC, nL = d->nL, nV = d->nV, nS = d->nS, nD = d->nD;
@@ -490,13 +551,31 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
     for (int k = 0; k < n; k++)
       for (int a : upper[k])
         for (int b : upper[k]) is_tgt[E.pos(a, b)] = 1;
+    // Numbering inside each class: SLOT-MAJOR over the pivots of a level — (level of the owning pivot m = min(row,
+    // col), diagonal / L / U, position of the other index in upper[m], m).  The factor tasks of a phase are ordered
+    // by (slot pair, pivot), so the 32 lanes of a half-wave read the same slot of 32 consecutive pivots: consecutive
+    // addresses, distinct LDS banks for the L, d and U operands (in CSR order they were 2.6-way conflicted on the
+    // chain; only the scattered targets still are).  `g_bank_aware` off = the old CSR order (tests compare both).
     E.id_of_pos.assign(nLU, -1);
-    int next = 0;
-    for (int cls = 0; cls < 3; cls++)
+    {
+      std::vector<int> posr(nLU);
+      for (int r = 0; r < n; r++)
+        for (int p = E.ptr[r]; p < E.ptr[r + 1]; p++) posr[p] = r;
+      std::vector<std::array<int64_t, 2>> key(nLU);
       for (int p = 0; p < nLU; p++) {
-        const int c = is_dyn[p] ? 0 : (is_tgt[p] ? 1 : 2);
-        if (c == cls) E.id_of_pos[p] = next++;
+        const int r = posr[p], c = E.col[p], m = std::min(r, c), o = std::max(r, c);
+        const int cls = is_dyn[p] ? 0 : (is_tgt[p] ? 1 : 2);
+        int64_t slot = 0;
+        if (o != m) slot = std::lower_bound(upper[m].begin(), upper[m].end(), o) - upper[m].begin();
+        const int kind = r == c ? 0 : (c < r ? 1 : 2);
+        if (g_bank_aware) key[p] = {((int64_t)cls << 40) | ((int64_t)hp.level[m] << 20) | ((int64_t)kind << 18) | slot, (int64_t)m};
+        else key[p] = {(int64_t)cls << 40, (int64_t)p};
       }
+      std::vector<int> ordp(nLU);
+      std::iota(ordp.begin(), ordp.end(), 0);
+      std::stable_sort(ordp.begin(), ordp.end(), [&](int a, int b) { return key[a] < key[b]; });
+      for (int i = 0; i < nLU; i++) E.id_of_pos[ordp[i]] = i;
+    }
     int nrest = 0;
     for (int p = 0; p < nLU; p++) nrest += (is_dyn[p] || is_tgt[p]) ? 1 : 0;
     hp.hdr.nRestore = nrest;
@@ -696,16 +775,24 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
     bool too_long = false;
     for (int l = 0; l < nLevels; l++) {  // factor phases: re-derive the grouped tasks of level l
       hp.ph_first.push_back((uint32_t)(hp.rec16.size() / 4));
-      struct Prod { uint32_t tgt, l, d, u; };
+      struct Prod { uint32_t tgt, l, d, u; int32_t si, sj, k; };  // si / sj: slots of the L / U operand in upper[k] (sj = -1: rhs)
       std::vector<Prod> prods;
-      for (int k : by_level[l])
-        for (int a : upper[k]) {
+      for (int k : by_level[l]) {
+        const std::vector<int> &S = upper[k];
+        for (int ia = 0; ia < (int)S.size(); ia++) {
+          const int a = S[ia];
           uint32_t le = (uint32_t)E.find(a, k);
-          for (int b : upper[k]) prods.push_back({(uint32_t)E.find(a, b), le, (uint32_t)diag[k], (uint32_t)E.find(k, b)});
-          prods.push_back({(uint32_t)(nLU + a), le, (uint32_t)diag[k], (uint32_t)(nLU + k)});
+          for (int ib = 0; ib < (int)S.size(); ib++)
+            prods.push_back({(uint32_t)E.find(a, S[ib]), le, (uint32_t)diag[k], (uint32_t)E.find(k, S[ib]), ia, ib, k});
+          prods.push_back({(uint32_t)(nLU + a), le, (uint32_t)diag[k], (uint32_t)(nLU + k), ia, -1, k});
         }
-      std::stable_sort(prods.begin(), prods.end(), [](const Prod &x, const Prod &y) { return x.tgt < y.tgt; });
-      struct UT { uint32_t t; bool recip; std::vector<uint32_t> tr; };
+      }
+      // grouped by target in MATRIX-POSITION order (independent of the entry numbering, see spicey_build_program)
+      auto poskey = [&](uint32_t t) -> uint64_t {
+        return (int)t >= nLU ? (((uint64_t)1 << 62) | t) : (((uint64_t)E.row_of_id[t] << 31) | (uint64_t)E.col_of_id[t]);
+      };
+      std::stable_sort(prods.begin(), prods.end(), [&](const Prod &x, const Prod &y) { return poskey(x.tgt) < poskey(y.tgt); });
+      struct UT { uint32_t t; bool recip; std::vector<uint32_t> tr; int32_t si, sj, k; };
       std::vector<UT> uts;
       for (size_t i = 0; i < prods.size();) {
         size_t j = i;
@@ -718,7 +805,7 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
           recip = E.col_of_id[t] == r && hp.level[r] == l + 1;
         }
         if (tr.size() / 3 > 255) too_long = true;
-        uts.push_back({t, recip, std::move(tr)});
+        uts.push_back({t, recip, std::move(tr), prods[i].si, prods[i].sj, prods[i].k});
         i = j;
       }
       // right-hand-side tasks first (a linear circuit's reused factorisation runs only those), then the same
@@ -727,7 +814,12 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
         const bool xr = (int)x.t >= nLU, yr = (int)y.t >= nLU;
         if (xr != yr) return xr;
         if (x.recip != y.recip) return x.recip > y.recip;
-        return x.tr.size() > y.tr.size();
+        if (x.tr.size() != y.tr.size()) return x.tr.size() > y.tr.size();
+        if (!g_bank_aware) return false;
+        // lanes = the same operand slots of consecutive pivots (see the entry numbering): conflict-free L, d, U reads
+        if (x.si != y.si) return x.si < y.si;
+        if (x.sj != y.sj) return x.sj < y.sj;
+        return x.k < y.k;
       });
       uint32_t nrhs = 0;
       for (auto &u : uts) nrhs += (int)u.t >= nLU ? 1u : 0u;

@@ -46,6 +46,11 @@ struct HostProgram {
 // run reports SPICEY_ERR_SINGULAR, like the reference throws at the first solve.
 int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err);
 
+// Diagnostics / tests: the operand-read LDS cycles of the compact records per solve vs the conflict-free minimum, and
+// a switch for the bank-aware second numbering pass (on by default).
+void spicey_bank_cost(const HostProgram &hp, int64_t *cycles, int64_t *ideal);
+void spicey_symbolic_set_bank_aware(bool on);
+
 // Resident (register) layout of the compact records for a workgroup of T threads with `rmax` slots per
 // thread.  Blob sections: res[rmax][T][4] u32, res_phase[T/64][rmax] i32, st_first[2L] u32, st_cnt[2L] u32.
 struct HostResident {

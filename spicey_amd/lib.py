@@ -90,7 +90,7 @@ class Handle:
 
     def __init__(self, flat: abi.FlatCircuit, device: int = 0, threads: int = 0, inst_per_wg: int = 0,
                  force_global: bool = False, profile: bool = False, interpreter: int = 0, geometry: int = 0, no_tail: bool = False, debug_empty_phases: int = 0, wgs_per_inst: int = 0,
-                 no_reuse: bool = False):
+                 no_reuse: bool = False, csr_numbering: bool = False):
         self.L = load()
         self.flat = flat
         opt = abi.SpiceyOptions()
@@ -99,7 +99,7 @@ class Handle:
         opt.interpreter = int(interpreter)
         opt.geometry = int(geometry)
         opt.wgs_per_inst = int(wgs_per_inst)
-        opt.debug = (1 if no_tail else 0) | (2 if no_reuse else 0) | (int(debug_empty_phases) << 8)
+        opt.debug = (1 if no_tail else 0) | (2 if no_reuse else 0) | (4 if csr_numbering else 0) | (int(debug_empty_phases) << 8)
         d = flat.desc()
         hp = C.c_void_p()
         rc = self.L.spicey_create(C.byref(d), C.byref(opt), C.byref(hp))

@@ -27,6 +27,8 @@ def lib():
         L.spicey_emul_resident.restype = C.c_int32
         L.spicey_emul_resident.argtypes = [C.POINTER(abi.SpiceyDesc), C.c_int32, C.c_int32, C.c_int32, i32p, C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), i32p]
+        L.spicey_emul_bank_cost.restype = C.c_int32
+        L.spicey_emul_bank_cost.argtypes = [C.POINTER(abi.SpiceyDesc), i64p]
         L.spicey_emul_ac.restype = C.c_int32
         L.spicey_emul_ac.argtypes = [C.POINTER(abi.SpiceyDesc), C.c_int32, C.c_int64, f64p, f64p, f64p, f64p, C.c_int32,
                                      C.POINTER(abi.SpiceyInfo)]
@@ -113,3 +115,12 @@ def resident_layout(flat: abi.FlatCircuit, T: int, rmax: int, max_tail: int):
     rc = L.spicey_emul_resident(C.byref(d), T, rmax, max_tail, _p(res_phase, C.c_int32), _p(res_valid, C.c_uint32), _p(ph_cnt, C.c_uint32),
                                 _p(st_cnt, C.c_uint32), _p(meta, C.c_int32))
     return rc, res_phase, res_valid, ph_cnt, st_cnt, meta
+
+
+def bank_cost(flat: abi.FlatCircuit):
+    """(cycles, ideal) of the records' operand reads without and with the bank-aware numbering pass."""
+    out = np.zeros(4, np.int64)
+    d = flat.desc()
+    rc = lib().spicey_emul_bank_cost(C.byref(d), _p(out, C.c_int64))
+    assert rc == 0
+    return (int(out[0]), int(out[1])), (int(out[2]), int(out[3]))
