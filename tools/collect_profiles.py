@@ -9,9 +9,9 @@ DST = os.path.join(REPO, "profiles")
 
 
 def one(pattern):
-    f = sorted(glob.glob(os.path.join(SRC, pattern), recursive=True))
+    f = sorted(glob.glob(os.path.join(SRC, pattern), recursive=True), key=os.path.getmtime)
     assert f, pattern
-    return f[0]
+    return f[-1]  # gpurun merges into gpurun_out/ without deleting earlier runs' files: take the newest
 
 
 def last_json_line(path):
