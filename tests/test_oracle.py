@@ -182,3 +182,34 @@ def test_to_precision6_matches_js_engine():
     big = np.tile(mat, (200, 1))  # 300 000 x 3: the multi-threaded path
     tb = np.tile(t, 200)
     assert format_tran_native(tb, big, [0, 1, 2], "h").split("\n")[1:] == [", ".join([g["strings"][k % n], g["strings"][100 + k % n], g["strings"][2000 + k % n], g["strings"][4000 + k % n]]) for k in range(len(tb))]
+
+
+def test_parser_matches_reference_on_tricky_netlists():
+    """spicey_amd/netlist.py against the reference's own parseNetlist (tests/golden/parser_cases.json, 101 snippets:
+    unit suffixes, titles / comments / continuations, source specifications incl. waveform samples, models, analysis
+    cards, and the text of every Error)."""
+    g = load_golden("parser_cases")
+    ts = g["ts"]
+    enc = lambda x: (("Infinity" if x > 0 else "-Infinity") if isinstance(x, float) and x in (float("inf"), float("-inf")) else
+                     ("NaN" if isinstance(x, float) and x != x else x))
+    bad = []
+    for idx, (text, want) in enumerate(zip(g["cases"], g["results"])):
+        try:
+            c = parseNetlist(text)
+            got = {
+                "nodes": c.nodes.rev,
+                "R": [[e.name, e.n1, e.n2, enc(e.R)] for e in c.R],
+                "C": [[e.name, e.n1, e.n2, enc(e.C), enc(e.vPrev)] for e in c.C],
+                "L": [[e.name, e.n1, e.n2, enc(e.L), enc(e.iPrev)] for e in c.L],
+                "V": [[e.name, e.n1, e.n2, enc(e.dc), enc(e.acMag), enc(e.acPhaseDeg), e.index,
+                       [enc(e.waveform(t)) for t in ts] if e.waveform else None] for e in c.V],
+                "S": [[e.name, e.n1, e.n2, e.ncPos, e.ncNeg, e.modelName, e.isOn,
+                       [e.model.name, enc(e.model.Ron), enc(e.model.Roff), enc(e.model.Von), enc(e.model.Voff)] if e.model else None] for e in c.S],
+                "D": [[e.name, e.nPlus, e.nMinus, e.modelName, enc(e.vdPrev), [e.model.name, enc(e.model.Is), enc(e.model.N)] if e.model else None] for e in c.D],
+                "analyses": c.analyses, "probes": c.probes, "skipped": c.skipped,
+            }
+        except Exception as e:  # noqa: BLE001 — the reference throws plain Errors; the message is what is pinned
+            got = {"error": str(e)}
+        if json.loads(json.dumps(got)) != want:
+            bad.append((idx, text, got, want))
+    assert not bad, "\n\n".join(f"case {i}: {t!r}\n got  {a}\n want {w}" for i, t, a, w in bad[:6]) + f"\n... {len(bad)} mismatches"
