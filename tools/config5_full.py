@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 exactly as written: the 10 000-node R/C/diode mesh (rcd_mesh(100), seed 3), `.tran 1e-6 0.1` =
+100 001 timesteps, ONE instance on one GPU (16 workgroups cooperating), every node voltage and every element current
+recorded into device buffers (8 GB + 25 GB).  Prints one JSON line; the first steps are checked against the oracle."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from spicey_amd import abi, synth
+from spicey_amd.netlist import parseNetlist
+from spicey_amd.lib import Handle
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=100)
+ap.add_argument("--tstop", default="0.1")
+ap.add_argument("--check-steps", type=int, default=3)
+args = ap.parse_args()
+t0 = time.time()
+ckt = parseNetlist(synth.rcd_mesh(args.rows, seed=3, tran=f".tran 1e-6 {args.tstop}"))
+dt, steps = abi.computeEffectiveTimeStep(ckt.analyses["tran"]["dt"], ckt.analyses["tran"]["tstop"])
+flat = abi.flatten(ckt)
+src_np = abi.source_table(ckt, dt, steps)
+t_host = time.time() - t0
+dev = torch.device("cuda:0")
+t0 = time.time()
+h = Handle(flat)
+info = h.info()
+t_create = time.time() - t0
+src = torch.as_tensor(src_np, device=dev)
+out_v = torch.empty((1, steps + 1, info["n_out"]), dtype=torch.float64, device=dev)
+out_i = torch.empty((1, steps + 1, info["n_cur"]), dtype=torch.float64, device=dev)
+print(f"config 5: n_var {info['n_var']} nnz_lu {info['nnz_lu']} levels {info['n_levels']} steps {steps} G {info['wgs_per_inst']} "
+      f"out {out_v.numel() * 8 / 1e9:.1f}+{out_i.numel() * 8 / 1e9:.1f} GB", file=sys.stderr, flush=True)
+t0 = time.time()
+h.run_device(steps, dt, src.data_ptr(), out_v.data_ptr(), out_i.data_ptr())
+rc = h.sync()
+wall = time.time() - t0
+assert rc == 0, h.error()
+rec = dict(config="BASELINE configs[4]: rcd_mesh(%d), %d timesteps, 1 instance" % (args.rows, steps), n_var=info["n_var"], nnz_lu=info["nnz_lu"],
+           levels=info["n_levels"], wgs_per_inst=info["wgs_per_inst"], threads=info["threads"], kernel_s=h.kernel_ms() / 1e3, wall_s=wall,
+           ms_per_step=h.kernel_ms() / (steps + 1), solves=h.solves(), solves_per_s=h.solves() / (h.kernel_ms() / 1e3),
+           host_prepare_s=t_host, create_s=t_create, finite=bool(torch.isfinite(out_v).all().item() and torch.isfinite(out_i).all().item()),
+           v_min=float(out_v.min().item()), v_max=float(out_v.max().item()))
+if args.check_steps > 0:
+    from oracle.pyoracle import OracleBackend
+    k = args.check_steps
+    t0 = time.time()
+    ref = OracleBackend().run(flat, k, dt, src_np[: k + 1], want_currents=False)
+    got = out_v[0, : k + 1].cpu().numpy()
+    rec["oracle_check_steps"] = k + 1
+    rec["oracle_check_s"] = time.time() - t0
+    rec["err_over_tol"] = float((np.abs(got - ref["out_v"][0]) / (1e-9 * np.abs(ref["out_v"][0]) + 1e-12)).max())
+print(json.dumps(rec), flush=True)
+h.close()
