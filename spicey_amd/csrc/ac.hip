@@ -55,7 +55,7 @@ struct SpiceyAcHandle {
   std::string err;
 };
 
-static std::string g_ac_err;
+static thread_local std::string g_ac_err;  // message of the calling thread's last failed spicey_ac_create
 
 extern "C" const char *spicey_ac_last_error(SpiceyAcHandle *h) { return h ? h->err.c_str() : g_ac_err.c_str(); }
 

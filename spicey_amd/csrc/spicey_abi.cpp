@@ -51,7 +51,7 @@ struct SpiceyHandle {
   std::string err;
 };
 
-static std::string g_err;
+static thread_local std::string g_err;  // message of the calling thread's last failed spicey_create (no handle to hang it on)
 
 #define HIPCHK(h, call)                                                                 \
   do {                                                                                  \
@@ -121,9 +121,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   SpiceyHandle *h = new SpiceyHandle();
   if (opt) h->opt = *opt;
   std::string err;
-  spicey_symbolic_set_bank_aware(!((h->opt.debug >> 2) & 1));  // diagnostics: bit 2 = plain CSR numbering of the entries
-  int32_t rc = spicey_build_program(desc, h->hp, err);
-  spicey_symbolic_set_bank_aware(true);
+  int32_t rc = spicey_build_program(desc, h->hp, err, !((h->opt.debug >> 2) & 1));  // diagnostics: bit 2 = plain CSR numbering
   if (rc != SPICEY_OK) {
     g_err = err;
     delete h;

@@ -327,10 +327,8 @@ int64_t spicey_algorithmic_bytes(const SpiceyDesc *d, int32_t nnzA, int32_t nnzL
          16 * ((int64_t)d->nC + d->nL + d->nD) + 8 * ((int64_t)d->n_nodes + etot);
 }
 
-static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err);
+static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool slot_major);
 
-static bool g_bank_aware = true;
-void spicey_symbolic_set_bank_aware(bool on) { g_bank_aware = on; }
 
 // LDS cycles the operand reads of the compact records cost per solve (every half-wave group and operand role: the
 // largest number of distinct addresses on one bank) and the conflict-free minimum (one per group and role).
@@ -369,16 +367,13 @@ void spicey_bank_cost(const HostProgram &hp, int64_t *cycles, int64_t *ideal) {
 // order.  For programs that run from LDS (16-bit records) both are compiled and the one whose operand reads cost fewer
 // LDS cycles is kept (chains: 2.65 -> 1.88 conflict factor; small meshes are sometimes better off in CSR order).
 // Circuits on the global-workspace path keep the CSR order: LDS banks do not matter there.
-int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err) {
+int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware) {
   hp = HostProgram();
-  const bool want = g_bank_aware;
-  g_bank_aware = false;
-  int32_t rc = build_program_impl(d, hp, err);
-  g_bank_aware = want;
-  if (rc != SPICEY_OK || hp.structurally_singular || !hp.hdr.has16 || !want) return rc;
+  int32_t rc = build_program_impl(d, hp, err, false);
+  if (rc != SPICEY_OK || hp.structurally_singular || !hp.hdr.has16 || !bank_aware) return rc;
   HostProgram alt;
   std::string err2;
-  if (build_program_impl(d, alt, err2) == SPICEY_OK && alt.hdr.has16) {
+  if (build_program_impl(d, alt, err2, true) == SPICEY_OK && alt.hdr.has16) {
     int64_t c0, i0, c1, i1;
     spicey_bank_cost(hp, &c0, &i0);
     spicey_bank_cost(alt, &c1, &i1);
@@ -387,7 +382,7 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
   return rc;
 }
 
-static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err) {
+static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, const bool slot_major) {
   if (!d) { err = "null descriptor"; return SPICEY_ERR_BAD_DESC; }
   if (d->abi_version != SPICEY_ABI_VERSION) { err = "abi_version mismatch"; return SPICEY_ERR_BAD_DESC; }
   const int nN = d->n_nodes, nR = d->nR, nC = d->nC, nL = d->nL, nV = d->nV, nS = d->nS, nD = d->nD;
@@ -555,7 +550,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     // col), diagonal / L / U, position of the other index in upper[m], m).  The factor tasks of a phase are ordered
     // by (slot pair, pivot), so the 32 lanes of a half-wave read the same slot of 32 consecutive pivots: consecutive
     // addresses, distinct LDS banks for the L, d and U operands (in CSR order they were 2.6-way conflicted on the
-    // chain; only the scattered targets still are).  `g_bank_aware` off = the old CSR order (tests compare both).
+    // chain; only the scattered targets still are).  slot_major off = the old CSR order (spicey_build_program compiles both and keeps the cheaper one).
     E.id_of_pos.assign(nLU, -1);
     {
       std::vector<int> posr(nLU);
@@ -568,7 +563,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
         int64_t slot = 0;
         if (o != m) slot = std::lower_bound(upper[m].begin(), upper[m].end(), o) - upper[m].begin();
         const int kind = r == c ? 0 : (c < r ? 1 : 2);
-        if (g_bank_aware) key[p] = {((int64_t)cls << 40) | ((int64_t)hp.level[m] << 20) | ((int64_t)kind << 18) | slot, (int64_t)m};
+        if (slot_major) key[p] = {((int64_t)cls << 40) | ((int64_t)hp.level[m] << 20) | ((int64_t)kind << 18) | slot, (int64_t)m};
         else key[p] = {(int64_t)cls << 40, (int64_t)p};
       }
       std::vector<int> ordp(nLU);
@@ -815,7 +810,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
         if (xr != yr) return xr;
         if (x.recip != y.recip) return x.recip > y.recip;
         if (x.tr.size() != y.tr.size()) return x.tr.size() > y.tr.size();
-        if (!g_bank_aware) return false;
+        if (!slot_major) return false;
         // lanes = the same operand slots of consecutive pivots (see the entry numbering): conflict-free L, d, U reads
         if (x.si != y.si) return x.si < y.si;
         if (x.sj != y.sj) return x.sj < y.sj;

@@ -44,12 +44,11 @@ struct HostProgram {
 // Builds the program for `d`'s topology.  Returns SPICEY_OK or SPICEY_ERR_BAD_DESC (err filled).
 // A structurally singular matrix is not an error here: hp.structurally_singular is set and the
 // run reports SPICEY_ERR_SINGULAR, like the reference throws at the first solve.
-int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err);
+int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware = true);
 
-// Diagnostics / tests: the operand-read LDS cycles of the compact records per solve vs the conflict-free minimum, and
-// a switch for the bank-aware second numbering pass (on by default).
+// Diagnostics / tests: the operand-read LDS cycles of the compact records per solve vs the conflict-free minimum
+// (spicey_build_program's `bank_aware` = false keeps the plain CSR numbering of the entries).
 void spicey_bank_cost(const HostProgram &hp, int64_t *cycles, int64_t *ideal);
-void spicey_symbolic_set_bank_aware(bool on);
 
 // Resident (register) layout of the compact records for a workgroup of T threads with `rmax` slots per
 // thread.  Blob sections: res[rmax][T][4] u32, res_phase[T/64][rmax] i32, st_first[2L] u32, st_cnt[2L] u32.

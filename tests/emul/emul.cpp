@@ -219,11 +219,9 @@ extern "C" int32_t spicey_emul_ac(const SpiceyDesc *d, int32_t T, int64_t n_freq
 // LDS bank cost of the compiled records with and without the bank-aware numbering pass (symbolic.cpp).
 extern "C" int32_t spicey_emul_bank_cost(const SpiceyDesc *d, int64_t *out4) {
   for (int pass = 0; pass < 2; pass++) {
-    spicey_symbolic_set_bank_aware(pass == 1);
     HostProgram hp;
     std::string err;
-    int32_t rc = spicey_build_program(d, hp, err);
-    spicey_symbolic_set_bank_aware(true);
+    int32_t rc = spicey_build_program(d, hp, err, pass == 1);
     if (rc != SPICEY_OK) return rc;
     spicey_bank_cost(hp, &out4[pass * 2], &out4[pass * 2 + 1]);
   }

@@ -382,3 +382,38 @@ def test_linear_circuits_reuse_factorisation_on_gpu(oracle_backend):
     nl = HipBackend()
     nl.run(f2, st2, dt2, src2)
     assert nl.info["factor_reuse"] == 0
+
+
+def test_distinct_handles_from_distinct_threads(oracle_backend):
+    """include/spicey_hip.h: a handle is not thread-safe, distinct handles may be used from distinct threads (each owns
+    its stream and device buffers; no globals).  Four threads, four different circuits, run concurrently, twice."""
+    import threading
+    from spicey_amd.lib import HipBackend
+    jobs = []
+    for kind, n, seed in (("rc_ladder", 300, 1), ("diode_chain", 200, 2), ("rc_ladder", 64, 3), ("diode_chain", 500, 4)):
+        flat, dt, steps, src = synth.chain_batch(kind, n, [seed, seed + 10], tran=".tran 1e-6 4e-5")
+        jobs.append((flat, dt, steps, src, oracle_backend.run(flat, steps, dt, src)))
+    results = [None] * len(jobs)
+    errors = []
+
+    def work(i):
+        try:
+            flat, dt, steps, src, _ = jobs[i]
+            be = HipBackend()
+            a = be.run(flat, steps, dt, src)
+            b = HipBackend().run(flat, steps, dt, src)
+            results[i] = (a, b)
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, (flat, dt, steps, src, ref) in enumerate(jobs):
+        a, b = results[i]
+        assert a["status"] == b["status"] == 0
+        assert np.array_equal(a["out_v"], b["out_v"]) and np.array_equal(a["out_i"], b["out_i"])
+        assert tol_ratio(a["out_v"], ref["out_v"]).max() <= 1.0 and tol_ratio(a["out_i"], ref["out_i"]).max() <= 1.0
