@@ -20,6 +20,11 @@ struct GpuExec {
   unsigned long long *prof;  // null unless phase profiling was requested
   __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
   __device__ __forceinline__ bool failed() const { return false; }
+  __device__ __forceinline__ bool serial_chain() const { return false; }
+  __device__ __forceinline__ int local_threads() const { return (int)blockDim.x; }
+  __device__ __forceinline__ void sync() {}
+  template <class F>
+  __device__ __forceinline__ void local_phase(F f) { phase(0, f); }
   template <class F>
   __device__ __forceinline__ void phase(int tag, F f) {
     long long t0 = 0;
@@ -78,6 +83,20 @@ struct GpuGroupExec {
   bool bad;
   __device__ __forceinline__ int threads() const { return G * (int)blockDim.x; }
   __device__ __forceinline__ bool failed() const { return bad; }
+  __device__ __forceinline__ bool serial_chain() const { return G > 1; }
+  __device__ __forceinline__ int local_threads() const { return (int)blockDim.x; }
+  __device__ __forceinline__ void sync() { barrier(); }
+  // a phase of workgroup 0 alone (the others fall through to the next group barrier): data it reads was published by
+  // the last group barrier, data it writes is read by its own waves (one CU, one L1) until the next group barrier
+  template <class F>
+  __device__ __forceinline__ void local_phase(F f) {
+    if (wgi == 0) {
+      int tid = (int)threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      f(tid);
+      __syncthreads();
+    }
+  }
   __device__ __forceinline__ void barrier() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();

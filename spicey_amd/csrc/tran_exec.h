@@ -1161,6 +1161,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
 template <int K, class Exec>
 SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R, WgCtx<K> &c, int wg) {
   TranPhases<K> ph{P, R, c, ex.threads()};
+  TranPhases<K> phl{P, R, c, ex.local_threads()};  // the same phases over ONE workgroup's threads (group mode)
   ex.phase(SPICEY_PH_PRO, [&](int tid) {
     if (tid == 0) { c.flags[0] = 0; c.flags[1] = 0; c.flags[2] = -1; }
     ph.p0_gstat(tid);
@@ -1182,9 +1183,20 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
         if (P.lvl_slice[l] == P.lvl_slice[l + 1]) continue;
         ex.phase(SPICEY_PH_U0 + (l < 31 ? l : 31), [&](int tid) { ph.u_level(tid, l, linear && step > 0); });
       }
-      for (int l = P.nLevels - 1; l >= 0; l--) {
-        if (P.bk_lvl_slice[l] == P.bk_lvl_slice[l + 1]) continue;
-        ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) { ph.k_level(tid, l); });
+      if (ex.serial_chain()) {
+        // Group mode: the backward levels carry little work (mesh 100^2: 172 k products over 297 levels) but each
+        // would cost a cross-workgroup barrier (~4.7 us): ONE workgroup of the group walks them with its own
+        // workgroup barriers, the others wait at the single group barrier behind the chain.
+        for (int l = P.nLevels - 1; l >= 0; l--) {
+          if (P.bk_lvl_slice[l] == P.bk_lvl_slice[l + 1]) continue;
+          ex.local_phase([&](int tid) { phl.k_level(tid, l); });
+        }
+        ex.sync();
+      } else {
+        for (int l = P.nLevels - 1; l >= 0; l--) {
+          if (P.bk_lvl_slice[l] == P.bk_lvl_slice[l + 1]) continue;
+          ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) { ph.k_level(tid, l); });
+        }
       }
       ex.phase(SPICEY_PH_K0, [&](int tid) { ph.k_scale(tid); });
       if (c.flags[1]) { code = 1; err_step = step; err_iter = iter; break; }

@@ -22,6 +22,20 @@ struct SeqExec {
   void *rr = nullptr;  // per-thread "registers" of the v2 interpreter: std::vector<Regs>*
   int threads() const { return T; }
   bool failed() const { return false; }
+  // group-mode emulation: `chain` makes the backward levels run as a serial chain over the first T / 2 threads only
+  // (what workgroup 0 of a two-workgroup group does on the GPU)
+  bool chain = false;
+  bool serial_chain() const { return chain; }
+  int local_threads() const { return chain ? T / 2 : T; }
+  void sync() {}
+  template <class F>
+  void local_phase(F f) {
+    const int n = local_threads();
+    if (!reverse)
+      for (int t = 0; t < n; t++) f(t);
+    else
+      for (int t = n - 1; t >= 0; t--) f(t);
+  }
   template <class Regs>
   Regs &regs(int tid) {
     return (*static_cast<std::vector<Regs> *>(rr))[tid];
@@ -47,7 +61,7 @@ struct SeqExec {
 };
 
 template <int K>
-void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T, bool reverse, int rmax) {
+void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T, bool reverse, int rmax, bool chain = false) {
   const int ngroups = (R.n_inst + K - 1) / K;
   std::vector<double> W((size_t)P.nW * K), u((size_t)(P.nU + 1) * K), gd((size_t)(P.nGdyn + 1) * K);
   std::vector<int32_t> ison((size_t)(P.nS + 1) * K), flags(4);
@@ -60,6 +74,7 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
       c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
     }
     SeqExec ex{T, reverse};
+    ex.chain = chain;
     if (rmax < 0) {
       spicey_tran_run<K>(ex, P, R, c, g);
     } else {
@@ -125,9 +140,9 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
   if (T <= 0 || (T & 63)) return SPICEY_ERR_BAD_DESC;
   if (rmax > 16 || (rmax >= 0 && (!P.has16 || K > 2))) return SPICEY_ERR_BAD_DESC;  // v2 supports K <= 2
   switch (K) {
-    case 1: run_groups<1>(hp, P, R, T, (reverse & 1) != 0, rmax); break;
-    case 2: run_groups<2>(hp, P, R, T, (reverse & 1) != 0, rmax); break;
-    case 4: run_groups<4>(hp, P, R, T, (reverse & 1) != 0, rmax); break;
+    case 1: run_groups<1>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0); break;
+    case 2: run_groups<2>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0); break;
+    case 4: run_groups<4>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0); break;
     default: return SPICEY_ERR_BAD_DESC;
   }
   int64_t tot = 0;

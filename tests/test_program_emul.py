@@ -504,3 +504,16 @@ def test_random_circuits_ac_program_vs_oracle(block, oracle_backend):
         assert (np.abs(got["out_i"] - ref["out_i"])[0] / (1e-9 * np.abs(ref["out_i"][0]) + ytol)).max() <= 1.0, seed
         checked += 1
     assert checked >= 20 and arbitrated <= 3
+
+
+@pytest.mark.parametrize("name", ["mesh6", "mesh9x5", "dchain20", "boost_probe", "half_bridge"])
+def test_backward_chain_on_one_workgroup_is_bit_identical(name):
+    """Group mode runs the backward levels as a serial chain on ONE workgroup's threads (emulated: half of the
+    threads): a different task -> thread mapping, the same arithmetic."""
+    flat, steps, dt, src = _inputs(name)
+    a = EmulBackend(1, 128).run(flat, steps, dt, src)
+    for rev in (False, True):
+        b = EmulBackend(1, 128, rev, chain=True).run(flat, steps, dt, src)
+        assert a["status"] == b["status"] == 0
+        assert np.array_equal(a["out_v"], b["out_v"]) and np.array_equal(a["out_i"], b["out_i"], equal_nan=True)
+        assert np.array_equal(a["iters"], b["iters"])
