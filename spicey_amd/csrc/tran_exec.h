@@ -1179,9 +1179,24 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
     int iter = 0;
     for (;;) {
       ex.phase(SPICEY_PH_B, [&](int tid) { ph.b_stamp(tid); });
-      for (int l = 0; l < P.nLevels; l++) {
-        if (P.lvl_slice[l] == P.lvl_slice[l + 1]) continue;
-        ex.phase(SPICEY_PH_U0 + (l < 31 ? l : 31), [&](int tid) { ph.u_level(tid, l, linear && step > 0); });
+      {
+        // Group mode: runs of narrow factor levels (<= 1024 tasks, one per thread: the last pivots of the top separator) also go to
+        // workgroup 0 alone; a group barrier separates such a run from the next level that everybody works on.
+        bool local_run = false;
+        for (int l = 0; l < P.nLevels; l++) {
+          const uint32_t nsl = P.lvl_slice[l + 1] - P.lvl_slice[l];
+          if (nsl == 0) continue;
+          if (ex.serial_chain() && nsl <= 16) {
+            ex.local_phase([&](int tid) { phl.u_level(tid, l, linear && step > 0); });
+            local_run = true;
+          } else {
+            if (local_run) ex.sync();
+            local_run = false;
+            ex.phase(SPICEY_PH_U0 + (l < 31 ? l : 31), [&](int tid) { ph.u_level(tid, l, linear && step > 0); });
+          }
+        }
+        // (a trailing local run flows straight into the backward chain below, which workgroup 0 runs as well)
+        if (local_run && !ex.serial_chain()) ex.sync();
       }
       if (ex.serial_chain()) {
         // Group mode: the backward levels carry little work (mesh 100^2: 172 k products over 297 levels) but each
