@@ -242,3 +242,20 @@ extern "C" int32_t spicey_emul_bank_cost(const SpiceyDesc *d, int64_t *out4) {
   }
   return SPICEY_OK;
 }
+
+// per-level slice counts of the factor / backward lists and pivots per level (diagnostics for tools/)
+extern "C" int32_t spicey_emul_level_stats(const SpiceyDesc *d, int32_t cap, int32_t *n_levels, int32_t *upd_slices, int32_t *bk_slices, int32_t *pivots) {
+  HostProgram hp;
+  std::string err;
+  int32_t rc = spicey_build_program(d, hp, err);
+  if (rc != SPICEY_OK) return rc;
+  *n_levels = hp.hdr.nLevels;
+  for (int l = 0; l < hp.hdr.nLevels && l < cap; l++) {
+    upd_slices[l] = (int32_t)(hp.lvl_slice[l + 1] - hp.lvl_slice[l]);
+    bk_slices[l] = (int32_t)(hp.bk_lvl_slice[l + 1] - hp.bk_lvl_slice[l]);
+    pivots[l] = 0;
+  }
+  for (int k = 0; k < hp.hdr.n; k++)
+    if (hp.level[k] < cap) pivots[hp.level[k]]++;
+  return SPICEY_OK;
+}
