@@ -144,8 +144,9 @@ struct NDOrder {
     // iterative over a work stack of sub-problems (vertex lists)
     std::vector<std::vector<int>> work;
     {
-      std::vector<int> all(n);
-      std::iota(all.begin(), all.end(), 0);
+      std::vector<int> all;  // vertices the caller has already ordered (owner -1) stay out
+      for (int v = 0; v < n; v++)
+        if (owner[v] != -1) all.push_back(v);
       work.push_back(all);
     }
     // Sub-problems must be ordered so that separators come AFTER both halves.  Use a recursive
@@ -458,8 +459,75 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   hp.hdr.nOut = nOut; hp.hdr.nCur = nR + nC + nL + nV + nS + nD;
 
   // ---- 2. zero-free diagonal ------------------------------------------------------------------
-  std::vector<int> row_of_col;
-  if (!max_transversal(n, cand, row_of_col)) {
+  // 2a. STRUCTURED matching (numerically safe static pivots, replaces what partial pivoting does in solveReal.ts:15-34):
+  // every source k is paired with one of its non-ground terminals n_k by a bipartite matching sources <-> nodes; column
+  // n_k takes the branch row j_k (pivot +-1), column j_k takes the KCL row of n_k (pivot +-1), every other node keeps its
+  // own KCL row.  A GROUNDED source's two pivots can never be touched by another elimination (its branch row and branch
+  // column hold a single entry each), so it may sit anywhere in the order.  A FLOATING source's pair is eliminated before
+  // everything else (all node columns n_k, then all branch columns j_k): the branch rows restricted to the matched nodes
+  // are the incidence matrix of a forest with a unique perfect matching, so every leading minor is +-1 and both pivots of
+  // every pair are exactly +-1 in any order; what remains is the conductance matrix of the circuit with those sources
+  // contracted (v(n_k) = v(m_k) + V_k) — a symmetric M-matrix, safe under any diagonal pivot order.  (With a generic
+  // transversal and the pair left inside the nested dissection, eliminating a neighbour first turned the +-1 pivot into
+  // 1 - g/g = 0: `V1 a b / R1 a b / R2 a 0` was reported singular.)
+  std::vector<int> row_of_col(n, -1);
+  std::vector<int> forced;  // vertices eliminated first: matched nodes of floating sources, then their branch unknowns
+  bool structured = true;
+  {
+    std::vector<int> node_of_src(nV, -1), src_of_node(nN, -1);
+    std::vector<std::vector<int>> src_at(nN);
+    std::vector<std::array<int, 2>> term(nV);
+    std::vector<int> deg(nN, 0);
+    for (int c = 0; c < nN; c++) deg[c] = (int)arow[c].size();
+    for (int k = 0; k < nV; k++) {
+      int i1 = d->V_n1[k] - 1, i2 = d->V_n2[k] - 1;
+      if (i1 == i2) { structured = false; break; }  // shorted source: empty branch row
+      // lower-degree terminal first: eliminating the matched node early makes a clique of its neighbours
+      if (i1 >= 0 && i2 >= 0 && deg[i2] < deg[i1]) std::swap(i1, i2);
+      if (i1 < 0) std::swap(i1, i2);
+      term[k] = {i1, i2};
+      if (i1 >= 0) src_at[i1].push_back(k);
+      if (i2 >= 0) src_at[i2].push_back(k);
+    }
+    std::vector<int> seen_s(nV, -1), seen_n(nN, -1);
+    // augment from a node: the node takes one of its sources, which may push that source's node elsewhere
+    std::function<bool(int, int)> try_node = [&](int node, int stamp) -> bool {
+      for (int s2 : src_at[node]) {
+        if (seen_s[s2] == stamp) continue;
+        seen_s[s2] = stamp;
+        const int other = node_of_src[s2];
+        if (other < 0 || try_node(other, stamp)) { node_of_src[s2] = node; src_of_node[node] = s2; return true; }
+      }
+      return false;
+    };
+    std::function<bool(int, int)> try_src = [&](int s2, int stamp) -> bool {
+      for (int t : term[s2]) {
+        if (t < 0 || seen_n[t] == stamp) continue;
+        seen_n[t] = stamp;
+        const int other = src_of_node[t];
+        if (other < 0 || try_src(other, stamp)) { node_of_src[s2] = t; src_of_node[t] = s2; return true; }
+      }
+      return false;
+    };
+    if (structured) {
+      // nodes without a structural diagonal (only sources attached) must be a source's matched node
+      for (int c = 0; c < nN && structured; c++)
+        if (!std::binary_search(arow[c].begin(), arow[c].end(), c) && !try_node(c, c)) structured = false;
+      for (int k = 0; k < nV && structured; k++)
+        if (node_of_src[k] < 0 && !try_src(k, k)) structured = false;
+    }
+    if (structured) {
+      for (int c = 0; c < nN; c++) row_of_col[c] = src_of_node[c] >= 0 ? nN + src_of_node[c] : c;
+      for (int k = 0; k < nV; k++) row_of_col[nN + k] = node_of_src[k];
+      for (int k = 0; k < nV; k++)
+        if (term[k][0] >= 0 && term[k][1] >= 0) forced.push_back(node_of_src[k]);
+      const size_t nf = forced.size();
+      for (size_t i = 0; i < nf; i++) forced.push_back(nN + src_of_node[forced[i]]);
+    }
+  }
+  // 2b. anything the structured matching cannot express (it fails exactly when sources form a loop or a node hangs on
+  // nothing but an over-subscribed source): generic maximum transversal; a failure there is a structurally singular matrix
+  if (!structured && !max_transversal(n, cand, row_of_col)) {
     hp.structurally_singular = true;
     // keep a trivially valid (identity) program so that the handle can exist; run() reports singular
     row_of_col.resize(n);
@@ -475,11 +543,29 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     for (int c2 : arow[row_of_col[c]])
       if (c2 != c) { g[c].push_back(c2); g[c2].push_back(c); }
   for (int c = 0; c < n; c++) sort_unique(g[c]);
-  NDOrder nd(g);
+  // the forced vertices leave the graph first (their fill joins their remaining neighbours); nested dissection orders the rest
+  Adj g2 = g;
+  std::vector<char> gone(n, 0);
+  for (int v : forced) {
+    std::vector<int> nb;
+    for (int w : g2[v])
+      if (!gone[w]) nb.push_back(w);
+    for (int a : nb)
+      for (int b : nb)
+        if (a != b) g2[a].push_back(b);
+    for (int a : nb) sort_unique(g2[a]);
+    gone[v] = 1;
+  }
+  NDOrder nd(g2);
+  for (int v : forced) nd.owner[v] = -1;
   nd.run();
-  if ((int)nd.order.size() != n) { err = "internal: ordering lost vertices"; return SPICEY_ERR_BAD_DESC; }
+  if (nd.order.size() + forced.size() != (size_t)n) { err = "internal: ordering lost vertices"; return SPICEY_ERR_BAD_DESC; }
   hp.cpos.assign(n, -1);
-  for (int p = 0; p < n; p++) hp.cpos[nd.order[p]] = p;
+  {
+    int p = 0;
+    for (int v : forced) hp.cpos[v] = p++;
+    for (int v : nd.order) hp.cpos[v] = p++;
+  }
   hp.rpos.assign(n, -1);
   for (int r = 0; r < n; r++) hp.rpos[r] = hp.cpos[col_of_row[r]];
 

@@ -5,7 +5,7 @@ pairs."""
 import random
 
 
-def random_netlist(seed: int, max_nodes: int = 10) -> str:
+def random_netlist(seed: int, max_nodes: int = 10, floating_sources: bool = False) -> str:
     rnd = random.Random(seed)
     n = rnd.randint(2, max_nodes)
     nodes = [f"n{i}" for i in range(1, n + 1)]
@@ -74,6 +74,32 @@ def random_netlist(seed: int, max_nodes: int = 10) -> str:
             a, b = pair()
             c, d = pair()
             lines.append(f"{name('S')} {a} {b} {c} {d} SW1")
+    if floating_sources:
+        # 1-3 sources between two non-ground nodes (own generator: the base circuit of a seed stays what it was), kept
+        # loop-free together with the grounded ones (a loop of ideal sources is singular in any MNA)
+        r2 = random.Random(seed * 7919 + 17)
+        comp = {nd: nd for nd in nodes + ["0"]}
+
+        def find(x):
+            while comp[x] != x:
+                x = comp[x]
+            return x
+
+        for sn in src_nodes:
+            comp[find(sn)] = find("0")
+        for _ in range(r2.randint(1, 3)):
+            a, b = r2.sample(nodes, 2) if n >= 2 else (nodes[0], nodes[0])
+            if find(a) == find(b):
+                continue
+            comp[find(a)] = find(b)
+            kind = r2.random()
+            if kind < 0.4:
+                w = f"PULSE(0 {r2.choice(['2', '-1.5', '0.7'])} {r2.choice(['0', '3e-6'])} 1e-6 1e-6 {r2.choice(['4e-6', '7e-6'])} 1.5e-5)"
+            elif kind < 0.6:
+                w = f"PWL(0 0 5e-6 {r2.choice(['1', '-2'])} 1.2e-5 0.5)"
+            else:
+                w = f"dc {r2.choice(['1', '0.3', '-2', '0'])}"
+            lines.append(f"{name('V')} {a} {b} {w}")
     lines.append(f".tran 1e-6 {rnd.choice(['2e-5', '1.5e-5', '3e-5'])}")
     lines.append(".end")
     return "\n".join(lines)

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import (GOLD, LARGE_GOLDENS, SMALL_GOLDENS, bits_equal, farr, fnum, golden_netlist, load_golden)
+from conftest import (GOLD, LARGE_GOLDENS, SINGULAR_GOLDENS, SMALL_GOLDENS, bits_equal, farr, fnum, golden_netlist, load_golden)
 from spicey_amd import abi
 from spicey_amd.netlist import parseNetlist
 from spicey_amd.simulate import SingularMatrixError, formatTranResult, simulateTRAN
@@ -68,7 +68,7 @@ def test_appendix_c_spot_values(oracle_backend):
     assert g["V_nodes"]["n2"][1] == 3.613634986544149 and g["V_nodes"]["n2"][200] == 0.7504015734687133
 
 
-@pytest.mark.parametrize("name", ["err_singular", "err_vloop"])
+@pytest.mark.parametrize("name", SINGULAR_GOLDENS)
 def test_singular_errors(name, oracle_backend):
     g = load_golden(name)
     assert g["error"] == "Singular matrix (real)"

@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import LARGE_GOLDENS, REPO, SMALL_GOLDENS, golden_netlist, load_golden
+from conftest import LARGE_GOLDENS, REPO, SINGULAR_GOLDENS, SMALL_GOLDENS, golden_netlist, load_golden
 from emul.pyemul import EmulBackend, symbolic
 from spicey_amd import abi, synth
 from spicey_amd.netlist import parseNetlist
@@ -129,7 +129,7 @@ def test_register_resident_batched_two_per_workgroup(oracle_backend):
         assert got["status"] == 0 and ratio(got["out_v"], ref["out_v"]).max() <= 1.0 and ratio(got["out_i"], ref["out_i"]).max() <= 1.0
 
 
-@pytest.mark.parametrize("name", ["err_singular", "err_vloop"])
+@pytest.mark.parametrize("name", SINGULAR_GOLDENS)
 def test_program_singular(name):
     flat, steps, dt, src = _inputs(name)
     got = EmulBackend(1, 64).run(flat, steps, dt, src)
@@ -346,6 +346,44 @@ def test_random_circuits_program_vs_oracle(block, oracle_backend):
             assert (np.abs(got["out_i"][fin] - ref["out_i"][fin]) / (1e-9 * np.abs(ref["out_i"][fin]) + 1e-12 * iscale)).max() <= 1.0, (seed, text)
         ran += 1
     assert ran == 25
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_circuits_with_floating_sources(block, oracle_backend):
+    """The same random netlists plus 1-3 sources between two non-ground nodes (a static pivot order has to
+    keep their +-1 pivots intact).  A device 'singular' that the reference does not raise is a failure; everything else
+    is held to the parity bar.  Skipped: seeds on which the REFERENCE's own switch iteration hits the cap."""
+    from random_circuits import random_netlist
+    ran = 0
+    for seed in range(block * 25, block * 25 + 25):
+        text = random_netlist(seed, floating_sources=True)
+        ckt = parseNetlist(text)
+        dt, steps = abi.computeEffectiveTimeStep(ckt.analyses["tran"]["dt"], ckt.analyses["tran"]["tstop"])
+        flat = abi.flatten(ckt)
+        src = abi.source_table(ckt, dt, steps)
+        ref = oracle_backend.run(flat, steps, dt, src)
+        if ref["status"] == 0 and ref["iters"].max() >= 20:
+            continue
+        for be in (EmulBackend(1, 64), EmulBackend(1, 64, True, 2), EmulBackend(1, 128, False, 16)):
+            got = be.run(flat, steps, dt, src)
+            assert got["status"] == ref["status"], (seed, got["detail"], ref["detail"], text)
+            if ref["status"] != 0:
+                continue
+            scale = max(1.0, float(np.nanmax(np.abs(ref["out_v"]))))
+            assert np.array_equal(got["iters"], ref["iters"]), (seed, text)
+            if (np.abs(got["out_v"] - ref["out_v"]) / (1e-9 * np.abs(ref["out_v"]) + 1e-12 * scale)).max() > 1.0:
+                # two fp64 solutions further apart than one budget (diodes pushed past their clamp by a source): the
+                # 80-bit replay of the reference algorithm says where the truth lies; this build must be within budget of it
+                import hp_reference
+                hp, _ = hp_reference.run(flat, steps, dt, src)
+                assert (np.abs(got["out_v"][0] - hp) / (1e-9 * np.abs(hp) + 1e-12 * scale)).max() <= 1.0, (seed, text)
+                continue
+            fin = np.isfinite(ref["out_i"])
+            assert np.array_equal(fin, np.isfinite(got["out_i"])), seed
+            iscale = max(1.0, float(np.abs(ref["out_i"][fin]).max())) if fin.any() else 1.0
+            assert (np.abs(got["out_i"][fin] - ref["out_i"][fin]) / (1e-9 * np.abs(ref["out_i"][fin]) + 1e-12 * iscale)).max() <= 1.0, (seed, text)
+        ran += 1
+    assert ran >= 20
 
 
 def test_random_circuit_outliers_arbitrated_in_extended_precision(oracle_backend):

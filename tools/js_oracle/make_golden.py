@@ -34,6 +34,9 @@ SMALL = {
     "vswitch_pwl": 1, "diode_switch": 2, "boost_probe": 1, "bridge_rectifier": 1, "bridge_bleed": 1, "star_hub": 1, "lc_tank": 1,
     "relay_osc": 1, "half_bridge": 2, "units_title": 1, "float_cap": 1, "steps_round": 1,
     "err_singular": 1, "err_vloop": 1,
+    # floating voltage sources (a static pivot order must not lose their +-1 pivots) and near-singular pivots
+    "fv_bridge": 1, "fv_cap": 1, "fv_hang": 1, "fv_diode": 1, "fv_chain": 2,
+    "near_sing_a": 1, "near_sing_b": 1, "near_sing_c": 1, "near_sing_d": 1, "near_sing_e": 1, "near_sing_f": 1,
 }
 # name -> generator spec
 SYNTH = {

@@ -28,7 +28,7 @@ sys.path.insert(0, REPO)
 from spicey_amd import synth  # noqa: E402
 
 NODE = ["node", "--harmony-nullish", "--harmony-optional-chaining", "--max-old-space-size=16000"]
-SMALL = ["ac_readme", "ac_rlc", "ac_two_src", "ac_err_r0", "ac_err_float", "ac_none"]
+SMALL = ["ac_readme", "ac_rlc", "ac_two_src", "ac_err_r0", "ac_err_float", "ac_none", "ac_fv"]
 SYNTH = {
     "ac_ladder30": ("rc_ladder", dict(n=30, seed=4, tran=".ac dec 10 1e3 1e8")),
     "ac_mesh6": ("rcd_mesh", dict(rows=6, seed=3, tran=".ac dec 5 1e4 1e9")),
