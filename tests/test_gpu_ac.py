@@ -17,7 +17,7 @@ def cratio(got, ref, rtol=1e-9, atol=1e-12):
     return np.abs(got - ref) / (rtol * np.abs(ref) + atol)
 
 
-@pytest.mark.parametrize("name", ["ac_readme", "ac_rlc", "ac_two_src", "ac_ladder30", "ac_mesh6"])
+@pytest.mark.parametrize("name", ["ac_readme", "ac_rlc", "ac_two_src", "ac_fv", "ac_ladder30", "ac_mesh6"])
 def test_ac_hip_vs_oracle_and_golden(name, oracle_backend):
     from spicey_amd.lib import HipBackend
     g = load_golden(name)

@@ -255,7 +255,7 @@ def test_product_does_not_touch_oracle():
 
 
 # ---- AC sweep: the device phase code (spicey_amd/csrc/ac_exec.h) on the CPU against the oracle ---------------------
-AC_GOLDENS = ["ac_readme", "ac_rlc", "ac_two_src", "ac_ladder30", "ac_mesh6"]
+AC_GOLDENS = ["ac_readme", "ac_rlc", "ac_two_src", "ac_fv", "ac_ladder30", "ac_mesh6"]
 
 
 def _ac_inputs(name):
