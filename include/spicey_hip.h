@@ -90,6 +90,7 @@ typedef struct SpiceyOptions {
   int32_t geometry;      /* v2 only. 0 auto; 1 = latency: one workgroup per CU, whole program in registers;
                             2 = throughput: two 512-thread workgroups per CU (<= 128 VGPRs, wide levels streamed) */
   int32_t debug;         /* diagnostics: bit 0 = no tail merge; bit 1 = refactor every step even for linear circuits;
+                            bit 2 = plain CSR numbering of the L+U entries (no LDS-bank-aware slot-major numbering);
                             bits 8.. = extra empty phases per solve */
   int32_t wgs_per_inst;  /* global-workspace path: workgroups (CUs) cooperating on one instance; 0 auto, 1 = none */
 } SpiceyOptions;

@@ -1214,6 +1214,9 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
         }
       }
       ex.phase(SPICEY_PH_K0, [&](int tid) { ph.k_scale(tid); });
+      // a cross-workgroup barrier that timed out inside this iteration leaves a partially computed workspace: nothing of
+      // it may be recorded or reported as a success (group mode only; the flag is sticky and uniform across the group)
+      if (ex.failed()) { code = 3; err_step = step; err_iter = iter; break; }
       if (c.flags[1]) { code = 1; err_step = step; err_iter = iter; break; }
       if (P.nS == 0) break;
       ex.phase(SPICEY_PH_S, [&](int tid) { ph.s_switches(tid); });
@@ -1234,6 +1237,7 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
           if (c.valid[k]) R.iters[(size_t)c.inst[k] * (size_t)(R.steps + 1) + (size_t)step] = iter + 1;
       ph.z_record(tid, step, linear);
     });
+    if (ex.failed()) { code = 3; err_step = step; break; }  // also covers the last step and runs with steps = 0
   }
   ex.phase(SPICEY_PH_PRO, [&](int tid) {
     if (tid == 0) {

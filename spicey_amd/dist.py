@@ -15,6 +15,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .launch import free_port, spawn_local_ranks  # noqa: F401  (re-exported; stdlib-only module, usable before any GPU call)
+
 
 def world() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -88,3 +90,27 @@ def gather_to_all(t: torch.Tensor) -> List[torch.Tensor]:
 def barrier() -> None:
     if world() > 1:
         dist.barrier()
+
+
+def gather_rows_to_root(t: torch.Tensor, n_total: int, dst: int = 0) -> Optional[torch.Tensor]:
+    """Result gather of the sharded batch: every rank holds the rows (instances) of its block of
+    `shard_range(n_total)`, `dst` receives all of them in instance order, [n_total, ...]; other ranks get None.
+    Each peer's block travels over its own link to the root (RCCL gather = grouped send/recv; per-link bound on xGMI).
+    Blocks of a block partition differ by at most one row: they are padded to the largest for the collective."""
+    w = world()
+    if w == 1:
+        return t
+    sizes = [len(shard_range(n_total, r, w)) for r in range(w)]
+    mx = max(sizes)
+    t = t.contiguous()
+    if t.shape[0] != sizes[rank()]:
+        raise ValueError(f"rank {rank()} holds {t.shape[0]} rows, its shard has {sizes[rank()]}")
+    if t.shape[0] < mx:
+        pad = torch.zeros((mx - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        t = torch.cat([t, pad], 0)
+    if rank() == dst:
+        parts = [torch.empty_like(t) for _ in range(w)]
+        dist.gather(t, parts, dst=dst)
+        return torch.cat([p[: sizes[r]] for r, p in enumerate(parts)], 0)
+    dist.gather(t, None, dst=dst)
+    return None

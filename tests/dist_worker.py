@@ -35,6 +35,12 @@ def main():
     assert res["status"] == 0
     np.save(os.path.join(out_dir, f"out_v_{r}.npy"), res["out_v"])
     np.save(os.path.join(out_dir, f"ids_{r}.npy"), np.array(list(mine)))
+    # probe-filtered result gather to rank 0 (bench.py does the same over RCCL): columns 0, 5, 23 of every instance
+    cols = torch.tensor([0, 5, 23])
+    g = sdist.gather_rows_to_root(torch.from_numpy(res["out_v"]).index_select(2, cols), n_total)
+    assert (g is None) == (r != 0)
+    if r == 0:
+        np.save(os.path.join(out_dir, "gathered.npy"), g.numpy())
     chk = sdist.gather_to_all(torch.tensor([res["out_v"][:, -1, :].sum()], dtype=torch.float64))
     total = sdist.sum_over_ranks(float(be.solves))
     tmax = sdist.max_over_ranks(float(r + 1))

@@ -230,6 +230,10 @@ def test_group_mode_workgroups_cooperate_on_one_instance(oracle_backend):
         if first is None:
             first = got
         assert np.array_equal(got["out_v"], first["out_v"]) and np.array_equal(got["out_i"], first["out_i"])
+    # shortest runs (a barrier failure in the last step must not be reported as success): steps = 0 and 1
+    for st in (0, 1):
+        short = HipBackend(force_global=True, wgs_per_inst=4).run(flat, st, dt, src[: st + 1])
+        assert short["status"] == 0 and np.array_equal(short["out_v"][0], first["out_v"][0][: st + 1])
     # batched: two instances, each with its own group of workgroups
     got2 = HipBackend(force_global=True, wgs_per_inst=4).run(flat.replicate(2), steps, dt, src)
     assert got2["status"] == 0
@@ -475,3 +479,68 @@ def test_distinct_handles_from_distinct_threads(oracle_backend):
         assert a["status"] == b["status"] == 0
         assert np.array_equal(a["out_v"], b["out_v"]) and np.array_equal(a["out_i"], b["out_i"])
         assert tol_ratio(a["out_v"], ref["out_v"]).max() <= 1.0 and tol_ratio(a["out_i"], ref["out_i"]).max() <= 1.0
+
+
+def _oracle_sample(kind, n, seeds, tran, oracle_backend):
+    flat, dt, steps, src = synth.chain_batch(kind, n, seeds, tran=tran)
+    return oracle_backend.run(flat, steps, dt, src)
+
+
+def test_config4_shape_256_distinct_rc_ladders(oracle_backend):
+    """BASELINE config 4 on one GPU: 256 INDEPENDENT 1000-node RC ladders (seeds 1..256: same topology, per-instance
+    r_k, c_k), 201 points, every voltage and current.  Nine sampled instances (first, last, seven in between) against
+    the oracle run one instance at a time; seed 1 also against the reference's own numbers (rc1000_200 golden);
+    factor reuse on (linear circuit) and off must agree bit for bit on the whole batch."""
+    from spicey_amd.lib import HipBackend
+    tran = ".tran 1e-06 0.00019999999999999998"
+    seeds = list(range(1, 257))
+    flat, dt, steps, src = synth.chain_batch("rc_ladder", 1000, seeds, tran=tran)
+    be = HipBackend()
+    got = be.run(flat, steps, dt, src)
+    assert got["status"] == 0, got["detail"]
+    assert be.info["n_workgroups"] == 256 and be.info["interpreter"] == 2 and be.info["factor_reuse"] == 1
+    assert got["solves"] == 256 * (steps + 1) and steps == 200
+    for s in (1, 2, 37, 64, 100, 128, 191, 255, 256):
+        ref = _oracle_sample("rc_ladder", 1000, [s], tran, oracle_backend)
+        assert tol_ratio(got["out_v"][s - 1], ref["out_v"][0]).max() <= 1.0, s
+        assert tol_ratio(got["out_i"][s - 1], ref["out_i"][0]).max() <= 1.0, s
+        assert tol_ratio(got["state"]["C_vprev"][s - 1], ref["state"]["C_vprev"][0]).max() <= 1.0, s
+    g = load_golden("rc1000_200")
+    for k, series in g["V_nodes"].items():
+        assert tol_ratio(got["out_v"][0][:, g["keysV"].index(k)], farr(series)).max() <= 1.0, k
+    for st, vec in g["V_steps"].items():
+        assert tol_ratio(got["out_v"][0][int(st)], farr(vec)).max() <= 1.0, st
+    # distinct seeds give distinct answers (no instance aliasing) ...
+    assert len({got["out_v"][i, -1, 500].tobytes() for i in range(256)}) == 256
+    # ... and refactoring every step reproduces the reused factors bit for bit across the whole batch
+    again = HipBackend(no_reuse=True).run(flat, steps, dt, src)
+    assert np.array_equal(again["out_v"], got["out_v"]) and np.array_equal(again["out_i"], got["out_i"])
+
+
+def test_bench_geometry_512_distinct_diode_chains(oracle_backend):
+    """The geometry bench.py times: 512 distinct-seed diode_chain(1000) instances, two 512-thread workgroups per CU
+    (geometry 2, chosen automatically at >= 2 x #CU instances), wide levels streamed.  201 points; nine sampled
+    instances against the oracle, seed 2 against the reference's own numbers (dchain1000_200 golden)."""
+    from spicey_amd.lib import HipBackend
+    tran = ".tran 1e-06 0.00019999999999999998"
+    seeds = list(range(1, 513))
+    flat, dt, steps, src = synth.chain_batch("diode_chain", 1000, seeds, tran=tran)
+    be = HipBackend()
+    got = be.run(flat, steps, dt, src)
+    assert got["status"] == 0, got["detail"]
+    assert be.info["geometry"] == 2 and be.info["threads"] == 512 and be.info["streamed_tasks"] > 0 and be.info["factor_reuse"] == 0
+    assert be.info["n_workgroups"] == 512 and got["solves"] == 512 * (steps + 1)
+    for s in (1, 2, 3, 129, 256, 257, 400, 511, 512):
+        ref = _oracle_sample("diode_chain", 1000, [s], tran, oracle_backend)
+        assert tol_ratio(got["out_v"][s - 1], ref["out_v"][0]).max() <= 1.0, s
+        assert tol_ratio(got["out_i"][s - 1], ref["out_i"][0]).max() <= 1.0, s
+        assert tol_ratio(got["state"]["D_vdprev"][s - 1], ref["state"]["D_vdprev"][0]).max() <= 1.0, s
+    g = load_golden("dchain1000_200")
+    for k, series in g["V_nodes"].items():
+        assert tol_ratio(got["out_v"][1][:, g["keysV"].index(k)], farr(series)).max() <= 1.0, k
+    for st, vec in g["I_steps"].items():
+        assert tol_ratio(got["out_i"][1][int(st)], farr(vec)).max() <= 1.0, st
+    assert len({got["out_v"][i, -1, 1].tobytes() for i in range(512)}) == 512
+    # the latency geometry (one 1024-thread workgroup per CU, everything resident) gives the same bits
+    lat = HipBackend(geometry=1).run(flat, steps, dt, src)
+    assert np.array_equal(lat["out_v"], got["out_v"]) and np.array_equal(lat["out_i"], got["out_i"])
