@@ -149,6 +149,16 @@ int32_t spicey_sync(SpiceyHandle *h);
 int32_t spicey_get_state(SpiceyHandle *h, double *C_vprev, double *L_iprev, double *D_vdprev,
                          int32_t *S_ison);
 
+/* State entering the NEXT run (the counterpart of spicey_get_state; the reference keeps this state on the caller's
+ * `ckt`, parseNetlist.ts:316,327,439,422, and a caller may rewrite it between two simulateTRAN calls).  HOST arrays
+ * [n_inst][n<kind>]; a NULL pointer leaves that kind as it is.  Blocking. */
+int32_t spicey_set_state(SpiceyHandle *h, const double *C_vprev, const double *L_iprev, const double *D_vdprev,
+                         const int32_t *S_ison);
+/* Back to the state the descriptor of spicey_create carried (kept in device memory): enqueued on `stream` (a
+ * hipStream_t, NULL = default stream) as device-to-device copies, no synchronisation — every spicey_run_device after
+ * it repeats the same transient instead of continuing the previous one. */
+int32_t spicey_reset_state(SpiceyHandle *h, void *stream);
+
 /* Total solves (= sum of iterations) executed by the last run, all instances. */
 int64_t spicey_last_solve_count(SpiceyHandle *h);
 /* Duration in ms of the last run's kernel, measured with HIP events on the launch stream. */

@@ -38,6 +38,8 @@ struct SpiceyHandle {
          *d_Dis = nullptr, *d_Dn = nullptr;
   double *d_Cv = nullptr, *d_Li = nullptr, *d_Dv = nullptr;
   int32_t *d_Son = nullptr;
+  double *d_Cv0 = nullptr, *d_Li0 = nullptr, *d_Dv0 = nullptr;  // the descriptor's state, for spicey_reset_state
+  int32_t *d_Son0 = nullptr;
   double *d_gstat = nullptr, *d_statv = nullptr, *d_rcoef = nullptr, *d_gW = nullptr, *d_dpar = nullptr;
   int32_t *d_status = nullptr;
   unsigned long long *d_solves = nullptr;
@@ -80,7 +82,7 @@ extern "C" void spicey_destroy(SpiceyHandle *h) {
   if (!h) return;
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
   void *ptrs[] = {h->d_res, h->d_blob, h->d_R, h->d_C, h->d_L, h->d_Sron, h->d_Sroff, h->d_Svon, h->d_Svoff, h->d_Dis, h->d_Dn, h->d_Cv,
-                  h->d_Li, h->d_Dv, h->d_Son, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_gsync, h->d_gflags, h->d_status, h->d_solves, h->d_prof};
+                  h->d_Li, h->d_Dv, h->d_Son, h->d_Cv0, h->d_Li0, h->d_Dv0, h->d_Son0, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_gsync, h->d_gflags, h->d_status, h->d_solves, h->d_prof};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -232,6 +234,10 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   UP(d_Li, L_iprev, ni * P.nL);
   UP(d_Dv, D_vdprev, ni * P.nD);
   UP(d_Son, S_ison, ni * P.nS);
+  UP(d_Cv0, C_vprev, ni * P.nC);
+  UP(d_Li0, L_iprev, ni * P.nL);
+  UP(d_Dv0, D_vdprev, ni * P.nD);
+  UP(d_Son0, S_ison, ni * P.nS);
 #undef UP
   const double *nodbl = nullptr;
   if ((rc = upload(h, &h->d_gstat, nodbl, ni * P.nGstat)) != SPICEY_OK) return fail(rc);
@@ -429,6 +435,34 @@ extern "C" int32_t spicey_get_state(SpiceyHandle *h, double *C_vprev, double *L_
   if (L_iprev && P.nL) HIPCHK(h, hipMemcpy(L_iprev, h->d_Li, ni * P.nL * sizeof(double), hipMemcpyDeviceToHost));
   if (D_vdprev && P.nD) HIPCHK(h, hipMemcpy(D_vdprev, h->d_Dv, ni * P.nD * sizeof(double), hipMemcpyDeviceToHost));
   if (S_ison && P.nS) HIPCHK(h, hipMemcpy(S_ison, h->d_Son, ni * P.nS * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return SPICEY_OK;
+}
+
+extern "C" int32_t spicey_set_state(SpiceyHandle *h, const double *C_vprev, const double *L_iprev, const double *D_vdprev,
+                                    const int32_t *S_ison) {
+  if (!h) return SPICEY_ERR_BAD_DESC;
+  int32_t rc = spicey_sync(h);
+  if (rc != SPICEY_OK && rc != SPICEY_ERR_SINGULAR) return rc;
+  const SpiceyProg &P = h->hp.hdr;
+  const size_t ni = (size_t)h->n_inst;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (C_vprev && P.nC) HIPCHK(h, hipMemcpy(h->d_Cv, C_vprev, ni * P.nC * sizeof(double), hipMemcpyHostToDevice));
+  if (L_iprev && P.nL) HIPCHK(h, hipMemcpy(h->d_Li, L_iprev, ni * P.nL * sizeof(double), hipMemcpyHostToDevice));
+  if (D_vdprev && P.nD) HIPCHK(h, hipMemcpy(h->d_Dv, D_vdprev, ni * P.nD * sizeof(double), hipMemcpyHostToDevice));
+  if (S_ison && P.nS) HIPCHK(h, hipMemcpy(h->d_Son, S_ison, ni * P.nS * sizeof(int32_t), hipMemcpyHostToDevice));
+  return SPICEY_OK;
+}
+
+extern "C" int32_t spicey_reset_state(SpiceyHandle *h, void *stream) {
+  if (!h) return SPICEY_ERR_BAD_DESC;
+  const SpiceyProg &P = h->hp.hdr;
+  const size_t ni = (size_t)h->n_inst;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (P.nC) HIPCHK(h, hipMemcpyAsync(h->d_Cv, h->d_Cv0, ni * P.nC * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (P.nL) HIPCHK(h, hipMemcpyAsync(h->d_Li, h->d_Li0, ni * P.nL * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (P.nD) HIPCHK(h, hipMemcpyAsync(h->d_Dv, h->d_Dv0, ni * P.nD * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (P.nS) HIPCHK(h, hipMemcpyAsync(h->d_Son, h->d_Son0, ni * P.nS * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   return SPICEY_OK;
 }
 

@@ -18,7 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPICEY_HIP_LIB") or os.path.join(_HERE, "libspicey_hip.so")  # same override as ts/spiceyHip.ts
 _LIB = None
 
-EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "spicey_get_state", "spicey_last_solve_count",
+EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "spicey_get_state", "spicey_set_state", "spicey_reset_state",
+           "spicey_last_solve_count",
            "spicey_last_kernel_ms", "spicey_get_info", "spicey_last_error", "spicey_destroy", "spicey_version",
            "spicey_debug_phase_cycles",
            "spicey_ac_create", "spicey_ac_run", "spicey_ac_get_info", "spicey_ac_last_kernel_ms", "spicey_ac_last_error", "spicey_ac_destroy",
@@ -48,6 +49,10 @@ def load():
     L.spicey_sync.argtypes = [vp]
     L.spicey_get_state.restype = C.c_int32
     L.spicey_get_state.argtypes = [vp, f64p, f64p, f64p, i32p]
+    L.spicey_set_state.restype = C.c_int32
+    L.spicey_set_state.argtypes = [vp, f64p, f64p, f64p, i32p]
+    L.spicey_reset_state.restype = C.c_int32
+    L.spicey_reset_state.argtypes = [vp, vp]
     L.spicey_last_solve_count.restype = C.c_int64
     L.spicey_last_solve_count.argtypes = [vp]
     L.spicey_last_kernel_ms.restype = C.c_double
@@ -166,6 +171,21 @@ class Handle:
         if rc != abi.OK:
             raise SpiceyNativeError(f"spicey_get_state failed ({rc}): {self.error()}")
         return st
+
+    def set_state(self, st: dict) -> None:
+        """State entering the next run: any of C_vprev / L_iprev / D_vdprev [n_inst][n] float64, S_ison int32."""
+        a = {k: (np.ascontiguousarray(st[k], dtype=np.int32 if k == "S_ison" else np.float64) if st.get(k) is not None else None)
+             for k in ("C_vprev", "L_iprev", "D_vdprev", "S_ison")}
+        rc = self.L.spicey_set_state(self.h, _p(a["C_vprev"], C.c_double), _p(a["L_iprev"], C.c_double), _p(a["D_vdprev"], C.c_double),
+                                     _p(a["S_ison"], C.c_int32))
+        if rc != abi.OK:
+            raise SpiceyNativeError(f"spicey_set_state failed ({rc}): {self.error()}")
+
+    def reset_state(self, stream: int = 0) -> None:
+        """Back to the state the handle was created with (device-to-device, enqueued on `stream`)."""
+        rc = self.L.spicey_reset_state(self.h, stream or None)
+        if rc != abi.OK:
+            raise SpiceyNativeError(f"spicey_reset_state failed ({rc}): {self.error()}")
 
     def close(self) -> None:
         if getattr(self, "h", None):
