@@ -8,6 +8,7 @@
 #define SPICEY_LDS_MAX 163840  // 160 KiB per CU on MI355X (MI355X_MICROARCH.md "Chip-level parameters")
 
 size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds, int tail_n = 0);
+size_t spicey_front_lds_bytes(const SpiceyProg &P);
 size_t spicey_gw_doubles_per_wg(const SpiceyProg &P, int K);
 hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bool lds, int grid, int threads, hipStream_t st);
 

@@ -16,8 +16,33 @@
 
 namespace {
 
+// one wave, `nlanes` lanes in lockstep through `nsteps` dependent steps (LDS operations of one wave execute in order, so
+// step s + 1 sees what step s wrote without a workgroup barrier); the other waves wait at the closing barrier
+template <class F>
+__device__ __forceinline__ void gpu_wave_lockstep(int nlanes, int nsteps, F f) {
+  int tid = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  if (tid < 64) {
+    for (int s = 0; s < nsteps; s++) {
+      if (tid < nlanes) f(tid, s);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+}
+
 struct GpuExec {
   unsigned long long *prof;  // null unless phase profiling was requested
+  double *lds_;              // scratch for the dense fronts (null when the program has none)
+  __device__ __forceinline__ int wg() const { return 0; }
+  __device__ __forceinline__ double *lds() const { return lds_; }
+  template <class F>
+  __device__ __forceinline__ void wg_phase(F f) { phase(0, f); }
+  template <class F>
+  __device__ __forceinline__ void wave_lockstep(int nlanes, int nsteps, F f) { gpu_wave_lockstep(nlanes, nsteps, f); }
+  __device__ __forceinline__ void front_post(unsigned int *, unsigned int) {}
+  __device__ __forceinline__ void front_wait(unsigned int *, unsigned int) {}
   __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
   __device__ __forceinline__ bool failed() const { return false; }
   __device__ __forceinline__ bool serial_chain() const { return false; }
@@ -66,7 +91,9 @@ __global__ void __launch_bounds__(1024) spicey_tran_kernel(SpiceyProg P, SpiceyR
     c.valid[k] = in < R.n_inst;
     c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
   }
-  GpuExec ex{R.prof ? R.prof + (size_t)wg * SPICEY_PH_SLOTS : nullptr};
+  // (front scratch behind the workspace / the flags: offsets from `smem` keep the LDS address space)
+  const size_t lds_off = LDS ? (((nW + nU + nG) * sizeof(double) + ((size_t)P.nS * K + 4) * sizeof(int32_t) + 15) & ~(size_t)15) : 64;
+  GpuExec ex{R.prof ? R.prof + (size_t)wg * SPICEY_PH_SLOTS : nullptr, (double *)(smem + lds_off)};
   spicey_tran_run<K>(ex, P, R, c, wg);
 }
 
@@ -81,6 +108,47 @@ struct GpuGroupExec {
   unsigned int *counter, *abortf;
   unsigned int epoch;
   bool bad;
+  double *lds_;
+  __device__ __forceinline__ int wg() const { return wgi; }
+  __device__ __forceinline__ double *lds() const { return lds_; }
+  // a phase of THIS workgroup alone (every workgroup of the group runs its own): workgroup barrier only
+  template <class F>
+  __device__ __forceinline__ void wg_phase(F f) {
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    f(tid);
+    __syncthreads();
+  }
+  template <class F>
+  __device__ __forceinline__ void wave_lockstep(int nlanes, int nsteps, F f) { gpu_wave_lockstep(nlanes, nsteps, f); }
+  // front hand-off between two workgroups of the group: the producer's stores are drained by every wave, the workgroup
+  // meets, lane 0 releases at agent scope and publishes the solve number; the consumer polls relaxed, acquires, and
+  // holds its workgroup's barrier until the invalidate has completed (MI355X_MICROARCH.md, valid forms)
+  __device__ __forceinline__ void front_post(unsigned int *flag, unsigned int value) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __device__ __forceinline__ void front_wait(unsigned int *flag, unsigned int value) {
+    if (threadIdx.x == 0) {
+      unsigned int spins = 0;
+      while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+        if (++spins > (1u << 22) || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) bad = true;
+  }
   __device__ __forceinline__ int threads() const { return G * (int)blockDim.x; }
   __device__ __forceinline__ bool failed() const { return bad; }
   __device__ __forceinline__ bool serial_chain() const { return G > 1; }
@@ -131,6 +199,7 @@ struct GpuGroupExec {
 
 template <int K>
 __global__ void __launch_bounds__(1024) spicey_tran_kernel_grp(SpiceyProg P, SpiceyRun R) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // scratch of the dense fronts
   WgCtx<K> c;
   const int G = R.wgs_per_group;
   const int grp = (int)blockIdx.x / G, wgi = (int)blockIdx.x % G;
@@ -148,7 +217,7 @@ __global__ void __launch_bounds__(1024) spicey_tran_kernel_grp(SpiceyProg P, Spi
     c.valid[k] = in < R.n_inst;
     c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
   }
-  GpuGroupExec ex{G, wgi, R.grp_sync + (size_t)grp * 4, R.grp_sync + (size_t)grp * 4 + 1, 0u, false};
+  GpuGroupExec ex{G, wgi, R.grp_sync + (size_t)grp * 4, R.grp_sync + (size_t)grp * 4 + 1, 0u, false, (double *)smem};
   spicey_tran_run<K>(ex, P, R, c, grp);
 }
 
@@ -269,11 +338,19 @@ hipError_t launch_t(const SpiceyProg &P, const SpiceyRun &R, int grid, int threa
 
 }  // namespace
 
+// LDS scratch of the dense fronts: the widest panel (U rows 16 x ld, L rows (Mp - 16) x 17, the 16 x 16 block of L and
+// the reciprocal pivots), which also covers the backward solve's vectors
+size_t spicey_front_lds_bytes(const SpiceyProg &P) {
+  if (P.nFronts <= 0) return 0;
+  return ((size_t)33 * (size_t)P.max_front_mp + 1024) * sizeof(double);
+}
+
 size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds, int tail_n) {
-  if (!lds) return 64;
+  if (!lds) return 64 + spicey_front_lds_bytes(P);
   size_t b = ((size_t)P.nW + P.nU + P.nGdyn) * K * sizeof(double) + ((size_t)P.nS * K + 4) * sizeof(int32_t);
   b = ((b + 15) & ~size_t(15)) + SPICEY_PH_SLOTS * sizeof(unsigned long long);  // + profiling accumulators
   b = ((b + 15) & ~size_t(15)) + (size_t)tail_n * 64 * 16;                          // + tail task records
+  b += spicey_front_lds_bytes(P);                                                    // + dense-front scratch (32-bit interpreter only)
   return (b + 15) & ~size_t(15);
 }
 
@@ -283,9 +360,15 @@ size_t spicey_gw_doubles_per_wg(const SpiceyProg &P, int K) {
 
 hipError_t spicey_launch_tran_grp(const SpiceyProg &P, const SpiceyRun &R, int K, int n_groups, int threads, hipStream_t st) {
   const int grid = n_groups * R.wgs_per_group;
+  const size_t lds = spicey_front_lds_bytes(P);
+  if (lds > 48 * 1024) {
+    hipError_t e = K == 1 ? hipFuncSetAttribute(reinterpret_cast<const void *>(spicey_tran_kernel_grp<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                          : hipFuncSetAttribute(reinterpret_cast<const void *>(spicey_tran_kernel_grp<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
   switch (K) {
-    case 1: hipLaunchKernelGGL(spicey_tran_kernel_grp<1>, dim3(grid), dim3(threads), 0, st, P, R); break;
-    case 2: hipLaunchKernelGGL(spicey_tran_kernel_grp<2>, dim3(grid), dim3(threads), 0, st, P, R); break;
+    case 1: hipLaunchKernelGGL(spicey_tran_kernel_grp<1>, dim3(grid), dim3(threads), lds, st, P, R); break;
+    case 2: hipLaunchKernelGGL(spicey_tran_kernel_grp<2>, dim3(grid), dim3(threads), lds, st, P, R); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -29,6 +29,22 @@
 #define SPICEY_R16_RECIP 0x02u
 #define SPICEY_R16_K 0x01u
 
+// Dense front of the upper elimination tree (large instances, fronts_exec.h): a supernode — `p` consecutive pivots
+// whose rows share one structure — with its `q` boundary unknowns, stored as a dense (Mp x ld) row-major block of the
+// per-instance front workspace.  Local index i in [0, p): pivot k0 + i; [p, Pp): identity padding; Pp + j: boundary
+// element j; column Mp: right-hand side.  Pp, Mp are multiples of 16 (panel / MFMA tile width), ld = Mp + 16.
+struct SpiceyFront {
+  int32_t k0, p, q;
+  int32_t Pp, Mp, ld;
+  int32_t parent;    // front id or -1
+  uint32_t rel0;     // fr_rel[rel0 + j]: local index IN THE PARENT of boundary element j (extend-add map)
+  uint32_t off;      // offset (doubles) of the block inside the front workspace
+  uint32_t asm0, asm_n;  // fr_asm[2 (asm0 + t)] = W index, [.. + 1] = local offset row * ld + col: entries the front takes over from W
+  uint32_t bnd0;     // fr_bnd[bnd0 + j]: pivot position of boundary element j
+  uint32_t child0, child_n;  // fr_child[child0 + t]: child fronts in assembly order
+  uint32_t pad0_, pad1_;
+};
+
 struct SpiceySlice {
   uint32_t off;  // offset (in uint32 words) of the slice's index block inside `pairs`
   uint32_t len;  // longest task of the slice (number of products)
@@ -109,6 +125,17 @@ struct SpiceyProg {
   int32_t nRec16;
   int32_t has16;             // 0 when nW >= 65536 (global-workspace path only)
 
+  // --- dense fronts (nFronts > 0): pivots of elimination-tree level >= front_cut are factored front by front
+  //     (multifrontal: assemble from W + children's contribution blocks, blocked dense LU in LDS, trailing update),
+  //     the levels below keep the task lists above.  bk level `front_cut` then holds the INTERFACE tasks: every row
+  //     below the cut receives its products with all upper unknowns in one phase.  one_slot: W index of a constant 1.0
+  //     (the "reciprocal diagonal" the interface / scaling tasks see for upper pivots, whose W[nLU + k] is x itself).
+  int32_t nFronts, front_cut;
+  int32_t one_slot, max_front_mp;
+  int64_t front_ws;  // doubles per instance
+  const SpiceyFront *fr;
+  const uint32_t *fr_asm, *fr_bnd, *fr_child, *fr_rel;
+
   // --- elements: terminal positions in W (x' slots), -1 = ground
   const int32_t *R_a, *R_b, *C_a, *C_b, *L_a, *L_b, *S_a, *S_b, *S_cp, *S_cn, *D_a, *D_b;
   const int32_t *V_x;   // [nV] W index of the branch current
@@ -170,4 +197,9 @@ struct SpiceyRun {
   int32_t *grp_flags;
   int32_t wgs_per_group;
   unsigned long long *prof;  // optional [n_workgroups][SPICEY_PH_SLOTS] shader-clock cycles per phase kind (diagnostics)
+  // dense fronts: workspace [n_groups][front_ws], per-workgroup schedule (front ids in postorder; fs_first[G + 1]),
+  // done flags [n_groups][2 * nFronts] (forward | backward; value = solve sequence number, zeroed before every launch)
+  double *front_ws;
+  const uint32_t *fs_first, *fs_list, *fs_owner;  // fs_owner[nFronts]: workgroup (of the group) that runs a front
+  unsigned int *front_flags;
 };

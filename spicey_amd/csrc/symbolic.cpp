@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <numeric>
@@ -328,7 +329,7 @@ int64_t spicey_algorithmic_bytes(const SpiceyDesc *d, int32_t nnzA, int32_t nnzL
          16 * ((int64_t)d->nC + d->nL + d->nD) + 8 * ((int64_t)d->n_nodes + etot);
 }
 
-static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool slot_major);
+static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool slot_major, int front_cut);
 
 
 // LDS cycles the operand reads of the compact records cost per solve (every half-wave group and operand role: the
@@ -368,13 +369,13 @@ void spicey_bank_cost(const HostProgram &hp, int64_t *cycles, int64_t *ideal) {
 // order.  For programs that run from LDS (16-bit records) both are compiled and the one whose operand reads cost fewer
 // LDS cycles is kept (chains: 2.65 -> 1.88 conflict factor; small meshes are sometimes better off in CSR order).
 // Circuits on the global-workspace path keep the CSR order: LDS banks do not matter there.
-int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware) {
+int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware, int front_cut) {
   hp = HostProgram();
-  int32_t rc = build_program_impl(d, hp, err, false);
+  int32_t rc = build_program_impl(d, hp, err, false, front_cut);
   if (rc != SPICEY_OK || hp.structurally_singular || !hp.hdr.has16 || !bank_aware) return rc;
   HostProgram alt;
   std::string err2;
-  if (build_program_impl(d, alt, err2, true) == SPICEY_OK && alt.hdr.has16) {
+  if (build_program_impl(d, alt, err2, true, 0) == SPICEY_OK && alt.hdr.has16) {
     int64_t c0, i0, c1, i1;
     spicey_bank_cost(hp, &c0, &i0);
     spicey_bank_cost(alt, &c1, &i1);
@@ -383,7 +384,7 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
   return rc;
 }
 
-static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, const bool slot_major) {
+static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, const bool slot_major, int front_cut) {
   if (!d) { err = "null descriptor"; return SPICEY_ERR_BAD_DESC; }
   if (d->abi_version != SPICEY_ABI_VERSION) { err = "abi_version mismatch"; return SPICEY_ERR_BAD_DESC; }
   const int nN = d->n_nodes, nR = d->nR, nC = d->nC, nL = d->nL, nV = d->nV, nS = d->nS, nD = d->nD;
@@ -614,7 +615,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     for (int r = 0; r < n; r++) E.col.insert(E.col.end(), rows[r].begin(), rows[r].end());
   }
   const int nLU = E.ptr[n];
-  hp.hdr.nLU = nLU; hp.hdr.nW = nLU + n; hp.hdr.nLevels = nLevels;
+  hp.hdr.nLU = nLU; hp.hdr.nW = nLU + n; hp.hdr.nLevels = nLevels;  // (nW grows by the constant-one slot when fronts are on, step 4b)
   {
     // classes of the CSR positions
     std::vector<uint8_t> is_dyn(nLU, 0), is_tgt(nLU, 0);
@@ -666,6 +667,111 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   }
   std::vector<int> diag(n);
   for (int k = 0; k < n; k++) diag[k] = E.find(k, k);
+
+  // ---- 4b. dense fronts above the cut (multifrontal upper tree, fronts_exec.h) -------------------------------
+  // Pivots of level >= Lc leave the level-scheduled task lists: consecutive pivots whose row structures nest
+  // (upper[k-1] = {k} + upper[k]: a separator of the nested dissection) form one supernode = one dense front.
+  int Lc = front_cut;
+  if (Lc < 0) {
+    // automatic: only where the long single-pivot chains of the top separators dominate (large, nonlinear circuits;
+    // a linear circuit reuses its factors and keeps the task lists)
+    Lc = (nD + nS > 0 && nLU >= 40000 && nLevels > 24 && !hp.structurally_singular) ? 12 : 0;
+    if (const char *e = getenv("SPICEY_FRONT_CUT")) Lc = atoi(e);  // experiments
+  }
+  if (Lc >= nLevels || hp.structurally_singular) Lc = 0;
+  std::vector<int> front_of(n, -1);
+  hp.fronts.clear(); hp.fr_asm.clear(); hp.fr_bnd.clear(); hp.fr_child.clear(); hp.fr_rel.clear(); hp.front_work.clear();
+  if (Lc > 0) {
+    auto pad16 = [](int x) { return (x + 15) & ~15; };
+    for (int k = 0; k < n; k++) {
+      if (hp.level[k] < Lc) continue;
+      const bool merge = k > 0 && front_of[k - 1] >= 0 && !upper[k - 1].empty() && upper[k - 1][0] == k &&
+                         upper[k - 1].size() == upper[k].size() + 1;
+      if (merge) {
+        front_of[k] = front_of[k - 1];
+        hp.fronts[front_of[k]].p++;
+      } else {
+        SpiceyFront f{};
+        f.k0 = k; f.p = 1;
+        front_of[k] = (int)hp.fronts.size();
+        hp.fronts.push_back(f);
+      }
+    }
+    bool ok = true;
+    uint64_t off = 0;
+    int max_mp = 0;
+    std::vector<std::vector<int>> kids(hp.fronts.size());
+    for (size_t fi = 0; fi < hp.fronts.size() && ok; fi++) {
+      SpiceyFront &f = hp.fronts[fi];
+      const std::vector<int> &B = upper[f.k0 + f.p - 1];
+      f.q = (int)B.size();
+      f.Pp = pad16(f.p); f.Mp = f.Pp + pad16(f.q); f.ld = f.Mp + 16;
+      f.parent = f.q ? front_of[B[0]] : -1;
+      if (f.q && f.parent < 0) ok = false;
+      if (f.parent >= 0) kids[f.parent].push_back((int)fi);
+      f.off = (uint32_t)off;
+      off += (uint64_t)f.Mp * f.ld;
+      max_mp = std::max(max_mp, f.Mp);
+      f.bnd0 = (uint32_t)hp.fr_bnd.size();
+      for (int b : B) hp.fr_bnd.push_back((uint32_t)b);
+      auto loc = [&](int x) -> int {  // local index of pivot position x in this front
+        if (x >= f.k0 && x < f.k0 + f.p) return x - f.k0;
+        auto it = std::lower_bound(B.begin(), B.end(), x);
+        if (it == B.end() || *it != x) { ok = false; return 0; }
+        return f.Pp + (int)(it - B.begin());
+      };
+      f.asm0 = (uint32_t)(hp.fr_asm.size() / 2);
+      double work = 0;
+      for (int i = 0; i < f.p; i++) {
+        const int k = f.k0 + i;
+        hp.fr_asm.push_back((uint32_t)diag[k]); hp.fr_asm.push_back((uint32_t)(i * f.ld + i));
+        for (int b : upper[k]) {
+          const int lb = loc(b);
+          hp.fr_asm.push_back((uint32_t)E.find(k, b)); hp.fr_asm.push_back((uint32_t)(i * f.ld + lb));
+          hp.fr_asm.push_back((uint32_t)E.find(b, k)); hp.fr_asm.push_back((uint32_t)(lb * f.ld + i));
+        }
+        hp.fr_asm.push_back((uint32_t)(nLU + k)); hp.fr_asm.push_back((uint32_t)(i * f.ld + f.Mp));
+        work += (double)upper[k].size() * (double)(upper[k].size() + 1);
+      }
+      f.asm_n = (uint32_t)(hp.fr_asm.size() / 2) - f.asm0;
+      hp.front_work.push_back(work + 64.0 * f.Mp);  // + a per-front overhead so that tiny fronts still count
+    }
+    if (off >= ((uint64_t)1 << 31) || max_mp > 448) ok = false;  // 32-bit offsets; panels of the largest front must fit LDS
+    for (size_t fi = 0; fi < hp.fronts.size() && ok; fi++) {
+      SpiceyFront &f = hp.fronts[fi];
+      f.child0 = (uint32_t)hp.fr_child.size();
+      f.child_n = (uint32_t)kids[fi].size();
+      for (int c : kids[fi]) hp.fr_child.push_back((uint32_t)c);
+      f.rel0 = (uint32_t)hp.fr_rel.size();
+      if (f.parent >= 0) {
+        const SpiceyFront &pf = hp.fronts[f.parent];
+        const std::vector<int> &PB = upper[pf.k0 + pf.p - 1];
+        for (int j = 0; j < f.q; j++) {
+          const int b = (int)hp.fr_bnd[f.bnd0 + j];
+          int l;
+          if (b >= pf.k0 && b < pf.k0 + pf.p) l = b - pf.k0;
+          else {
+            auto it = std::lower_bound(PB.begin(), PB.end(), b);
+            if (it == PB.end() || *it != b) { ok = false; break; }
+            l = pf.Pp + (int)(it - PB.begin());
+          }
+          hp.fr_rel.push_back((uint32_t)l);
+        }
+      }
+    }
+    if (!ok) {  // structure the dense kernels cannot take: keep the task lists for everything
+      Lc = 0;
+      hp.fronts.clear(); hp.fr_asm.clear(); hp.fr_bnd.clear(); hp.fr_child.clear(); hp.fr_rel.clear(); hp.front_work.clear();
+      std::fill(front_of.begin(), front_of.end(), -1);
+    } else {
+      hp.hdr.front_ws = (int64_t)off;
+      hp.hdr.max_front_mp = max_mp;
+    }
+  }
+  hp.hdr.nFronts = (int32_t)hp.fronts.size();
+  hp.hdr.front_cut = Lc;
+  hp.hdr.one_slot = nLU + n;
+  if (Lc > 0) hp.hdr.nW = nLU + n + 1;  // + the constant-one slot
 
   // ---- 5a. stamp lists --------------------------------------------------------------------------
   auto ent = [&](int r_orig, int c_orig) { return E.find(hp.rpos[r_orig], hp.cpos[c_orig]); };
@@ -756,6 +862,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     // (target, pivot, L entry, U entry) tuples, grouped by target in pivot order
     struct Prod { uint32_t tgt, l, d, u; };
     std::vector<Prod> prods;
+    if (Lc > 0 && l >= Lc) { hp.lvl_slice.push_back((uint32_t)hp.upd_slice.size()); continue; }  // factored as dense fronts
     for (int k : by_level[l]) {
       const std::vector<int> &S = upper[k];
       for (int a : S) {
@@ -777,7 +884,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
       if ((int)t < nLU) {
         // diagonal that becomes final now?
         const int r = E.row_of_id[t];
-        if (E.col_of_id[t] == r && hp.level[r] == l + 1) t |= SPICEY_TGT_RECIP;
+        if (E.col_of_id[t] == r && hp.level[r] == l + 1 && !(Lc > 0 && hp.level[r] >= Lc)) t |= SPICEY_TGT_RECIP;  // (a front inverts its own pivots)
       }
       tasks.emplace_back(t, std::move(flat));
       i = j;
@@ -801,10 +908,20 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   for (int l = 0; l < nLevels; l++) {
     struct Prod { uint32_t tgt, l, d, u; };
     std::vector<Prod> prods;
-    for (int k : by_level[l])
+    if (Lc > 0 && l > Lc) { hp.bk_lvl_slice.push_back((uint32_t)hp.bk_slice.size()); continue; }
+    // with fronts, "level Lc" holds the INTERFACE: every row below the cut receives its products with ALL upper
+    // unknowns (solved by the fronts: W[nLU + k] = x[k], diagonal operand = the constant-one slot), highest level first
+    const int l_hi = (Lc > 0 && l == Lc) ? nLevels - 1 : l;
+    for (int ll = l_hi; ll >= l; ll--)
+    for (int k : by_level[ll])
       for (int p = E.ptr[k]; p < E.ptr[k + 1]; p++) {
         const int r = E.col[p];
         if (r >= k) break;  // columns of row k left of the diagonal = rows r with U[r][k] != 0
+        if (Lc > 0 && ll >= Lc) {
+          if (hp.level[r] >= Lc) continue;  // upper rows are solved inside the fronts
+          prods.push_back({(uint32_t)(nLU + r), (uint32_t)(nLU + k), (uint32_t)hp.hdr.one_slot, (uint32_t)E.find(r, k)});
+          continue;
+        }
         prods.push_back({(uint32_t)(nLU + r), (uint32_t)(nLU + k), (uint32_t)diag[k], (uint32_t)E.find(r, k)});
       }
     std::stable_sort(prods.begin(), prods.end(), [](const Prod &x, const Prod &y) { return x.tgt < y.tgt; });
@@ -822,10 +939,13 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   }
   hp.hdr.nBkSlices = (int32_t)hp.bk_slice.size();
   hp.bk_d.assign(diag.begin(), diag.end());  // [n]: entry id of every pivot's (reciprocal) diagonal
+  if (Lc > 0)
+    for (int k = 0; k < n; k++)
+      if (hp.level[k] >= Lc) hp.bk_d[k] = (uint32_t)hp.hdr.one_slot;  // the fronts leave x itself in W[nLU + k]
 
   // ---- 5c'. compact 16-bit records of the same tasks, phases in execution order -------------------
   hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear(); hp.ph_rhs.clear();
-  hp.hdr.has16 = (nLU + n) < 65535 ? 1 : 0;  // 0xFFFF = ground in the packed terminal words
+  hp.hdr.has16 = ((nLU + n) < 65535 && Lc == 0) ? 1 : 0;  // 0xFFFF = ground in the packed terminal words; fronts run under the 32-bit interpreter
   if (hp.hdr.has16) {
     auto emit_u = [&](uint32_t tgt, bool recip, const std::vector<uint32_t> &tr) {  // tr = (l,d,u)*
       const uint32_t cnt = (uint32_t)(tr.size() / 3);
@@ -1036,6 +1156,11 @@ void HostProgram::pack() {
   add_section(blob, offsets, rowx);      // 43
   add_section(blob, offsets, R_ab); add_section(blob, offsets, C_ab);  // 44 45
   add_section(blob, offsets, L_ab); add_section(blob, offsets, D_ab);  // 46 47
+  add_section(blob, offsets, fronts);    // 48
+  add_section(blob, offsets, fr_asm);    // 49
+  add_section(blob, offsets, fr_bnd);    // 50
+  add_section(blob, offsets, fr_child);  // 51
+  add_section(blob, offsets, fr_rel);    // 52
 }
 
 SpiceyProg HostProgram::bind(const void *base) const {
@@ -1056,6 +1181,8 @@ SpiceyProg HostProgram::bind(const void *base) const {
   p.rec16 = u32(34); p.ovf16 = (const uint16_t *)(b + offsets[35]); p.ph_first = u32(36); p.ph_cnt = u32(37);
   p.ent_dd = u32(38); p.dynx_ent = u32(39); p.dynx_ptr = u32(40); p.dynx_idx = u32(41); p.row_desc = u32(42); p.rowx = u32(43);
   p.R_ab = u32(44); p.C_ab = u32(45); p.L_ab = u32(46); p.D_ab = u32(47);
+  p.fr = (const SpiceyFront *)(b + offsets[48]);
+  p.fr_asm = u32(49); p.fr_bnd = u32(50); p.fr_child = u32(51); p.fr_rel = u32(52);
   return p;
 }
 
@@ -1161,4 +1288,69 @@ SpiceyResident HostResident::bind(const void *base) const {
   r.tail_first = tail_first;
   r.tail_n = tail_n;
   return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Front schedule: proportional mapping.  The roots share the G workgroups by subtree work; a front whose subtree owns
+// the workgroup range [a, b) runs on workgroup a after its children, which split [a, b) among themselves by work
+// (largest first; a child may get an empty share, it then runs on a too).  Lists are in global postorder, so a
+// workgroup never waits for a front that is scheduled behind one of its own.
+void spicey_build_front_schedule(const HostProgram &hp, int G, std::vector<uint32_t> &first, std::vector<uint32_t> &list) {
+  const int nf = (int)hp.fronts.size();
+  G = std::max(G, 1);
+  first.assign((size_t)G + 1, 0u);
+  list.clear();
+  if (nf == 0) return;
+  std::vector<double> sub(nf, 0.0);
+  for (int f = 0; f < nf; f++) sub[f] = hp.front_work[f];
+  for (int f = 0; f < nf; f++)  // children precede parents (fronts are numbered in pivot order)
+    if (hp.fronts[f].parent >= 0) sub[hp.fronts[f].parent] += sub[f];
+  std::vector<int> owner(nf, 0);
+  std::vector<int> order;  // global postorder
+  order.reserve(nf);
+  struct Item { int f, a, b, stage; };
+  std::vector<Item> st;
+  // virtual root over the real roots
+  std::vector<int> roots;
+  for (int f = 0; f < nf; f++)
+    if (hp.fronts[f].parent < 0) roots.push_back(f);
+  auto split = [&](const std::vector<int> &kids, int a, int b, std::vector<std::array<int, 2>> &ranges) {
+    // contiguous shares of [a, b) proportional to subtree work, in the children's own order
+    ranges.assign(kids.size(), {a, a});
+    double tot = 0;
+    for (int c : kids) tot += sub[c];
+    const int w = b - a;
+    double acc = 0;
+    int lo = a;
+    for (size_t i = 0; i < kids.size(); i++) {
+      acc += sub[kids[i]];
+      int hi = (i + 1 == kids.size()) ? b : a + (int)(acc / std::max(tot, 1e-300) * w + 0.5);
+      hi = std::min(std::max(hi, lo), b);
+      ranges[i] = {lo, hi};
+      lo = hi;
+    }
+    // a child with an empty share runs on the workgroup where its share would start (clamped into [a, b))
+    for (auto &r : ranges)
+      if (r[0] == r[1]) { r[0] = std::min(r[0], b - 1); r[1] = r[0] + 1; }
+  };
+  std::function<void(int, int, int)> visit = [&](int f, int a, int b) {
+    owner[f] = a;
+    std::vector<int> kids(hp.fr_child.begin() + hp.fronts[f].child0, hp.fr_child.begin() + hp.fronts[f].child0 + hp.fronts[f].child_n);
+    std::vector<std::array<int, 2>> ranges;
+    split(kids, a, b, ranges);
+    for (size_t i = 0; i < kids.size(); i++) visit(kids[i], ranges[i][0], ranges[i][1]);
+    order.push_back(f);
+  };
+  {
+    std::vector<std::array<int, 2>> ranges;
+    split(roots, 0, G, ranges);
+    for (size_t i = 0; i < roots.size(); i++) visit(roots[i], ranges[i][0], ranges[i][1]);
+  }
+  std::vector<std::vector<uint32_t>> per(G);
+  for (int f : order) per[owner[f]].push_back((uint32_t)f);
+  for (int w = 0; w < G; w++) {
+    first[w] = (uint32_t)list.size();
+    list.insert(list.end(), per[w].begin(), per[w].end());
+  }
+  first[G] = (uint32_t)list.size();
 }

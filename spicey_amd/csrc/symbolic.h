@@ -32,6 +32,10 @@ struct HostProgram {
   std::vector<uint16_t> ovf16;
   std::vector<uint32_t> ent_dd, dynx_ent, dynx_ptr, dynx_idx, row_desc, rowx, R_ab, C_ab, L_ab, D_ab;
   std::vector<int32_t> R_a, R_b, C_a, C_b, L_a, L_b, S_a, S_b, S_cp, S_cn, D_a, D_b, V_x, out_x;
+  // dense fronts above the cut (empty when hdr.nFronts == 0)
+  std::vector<SpiceyFront> fronts;
+  std::vector<uint32_t> fr_asm, fr_bnd, fr_child, fr_rel;
+  std::vector<double> front_work;  // multiply-adds of each front's partial factorisation (for the schedule)
 
   // Serialise all arrays into one blob (16-byte aligned sections) and return a SpiceyProg whose
   // pointers are `base + offset`.  `base` may be a device address: the blob is then memcpy'd there.
@@ -44,7 +48,14 @@ struct HostProgram {
 // Builds the program for `d`'s topology.  Returns SPICEY_OK or SPICEY_ERR_BAD_DESC (err filled).
 // A structurally singular matrix is not an error here: hp.structurally_singular is set and the
 // run reports SPICEY_ERR_SINGULAR, like the reference throws at the first solve.
-int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware = true);
+// front_cut: elimination-tree level from which pivots are factored as dense fronts (fronts_exec.h); 0 = no fronts,
+// -1 = automatic (large nonlinear circuits only).
+int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware = true, int front_cut = 0);
+
+// Front schedule for G cooperating workgroups (proportional mapping of the front tree: a subtree's workgroup range is
+// split among its children by work; a front runs on the first workgroup of its range once its children are done).
+// first[G + 1], list[nFronts]: workgroup w executes list[first[w] .. first[w + 1]) in that order (global postorder).
+void spicey_build_front_schedule(const HostProgram &hp, int G, std::vector<uint32_t> &first, std::vector<uint32_t> &list);
 
 // Diagnostics / tests: the operand-read LDS cycles of the compact records per solve vs the conflict-free minimum
 // (spicey_build_program's `bank_aware` = false keeps the plain CSR numbering of the entries).

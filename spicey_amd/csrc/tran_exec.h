@@ -1156,6 +1156,8 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
   });
 }
 
+#include "fronts_exec.h"
+
 // The whole run of one workgroup.  Exec supplies `phase(f)` (run f(tid) for every thread, then
 // barrier) and `threads()`.  All control flow is workgroup-uniform: flags are read after barriers.
 template <int K, class Exec>
@@ -1174,6 +1176,11 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
   int32_t err_iter = 0;
   if (c.flags[1]) { code = 1; }
   const bool linear = P.nD == 0 && P.nS == 0 && P.nDynEnt == 0 && !R.no_reuse;  // see spicey_tran_run_v2
+  // dense fronts above the cut (K = 1 only; the host enables them for nonlinear circuits, so `linear` is false then)
+  const bool use_fronts = K == 1 && P.nFronts > 0 && R.front_ws != nullptr;
+  FrontsRun<Exec> fr{ex, P, R, c.W, c.flags, c.inst[0], c.valid[0], use_fronts ? R.front_ws + (size_t)wg * (size_t)P.front_ws : nullptr,
+                     use_fronts ? R.front_flags + (size_t)wg * 2 * (size_t)P.nFronts : nullptr, ex.local_threads()};
+  unsigned int fepoch = 0;
   for (int64_t step = 0; step <= R.steps && code == 0; step++) {
     if (ex.failed()) { code = 3; err_step = step; break; }  // a cross-workgroup barrier timed out (group mode only)
     int iter = 0;
@@ -1196,7 +1203,16 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
           }
         }
         // (a trailing local run flows straight into the backward chain below, which workgroup 0 runs as well)
-        if (local_run && !ex.serial_chain()) ex.sync();
+        if (local_run && (!ex.serial_chain() || use_fronts)) ex.sync();
+      }
+      if (use_fronts) {
+        // upper tree: every workgroup sweeps its share of the fronts up, then down (flags between workgroups, no group
+        // barrier inside); one group barrier afterwards publishes the upper unknowns to the levels below the cut
+        fepoch++;
+        fr.forward(fepoch);
+        fr.backward(fepoch);
+        ex.local_phase([&](int tid) { if (tid == 0) c.W[(size_t)P.one_slot * K] = 1.0; });
+        ex.sync();
       }
       if (ex.serial_chain()) {
         // Group mode: the backward levels carry little work (mesh 100^2: 172 k products over 297 levels) but each
@@ -1204,6 +1220,10 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
         // workgroup barriers, the others wait at the single group barrier behind the chain.
         for (int l = P.nLevels - 1; l >= 0; l--) {
           if (P.bk_lvl_slice[l] == P.bk_lvl_slice[l + 1]) continue;
+          if (use_fronts && l == P.front_cut) {  // the interface phase is wide (every row below the cut): all workgroups
+            ex.phase(SPICEY_PH_K0 + 31, [&](int tid) { ph.k_level(tid, l); });
+            continue;
+          }
           ex.local_phase([&](int tid) { phl.k_level(tid, l); });
         }
         ex.sync();

@@ -26,6 +26,23 @@ struct SeqExec {
   // (what workgroup 0 of a two-workgroup group does on the GPU)
   bool chain = false;
   bool serial_chain() const { return chain; }
+  // dense fronts: the emulator is ONE workgroup (every front in postorder, no hand-offs)
+  std::vector<double> lds_buf;
+  int wg() const { return 0; }
+  double *lds() { return lds_buf.data(); }
+  template <class F>
+  void wg_phase(F f) { local_phase(f); }
+  template <class F>
+  void wave_lockstep(int nlanes, int nsteps, F f) {
+    for (int s = 0; s < nsteps; s++) {
+      if (!reverse)
+        for (int t = 0; t < nlanes; t++) f(t, s);
+      else
+        for (int t = nlanes - 1; t >= 0; t--) f(t, s);
+    }
+  }
+  void front_post(unsigned int *, unsigned int) {}
+  void front_wait(unsigned int *, unsigned int) {}
   int local_threads() const { return chain ? T / 2 : T; }
   void sync() {}
   template <class F>
@@ -75,6 +92,7 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
     }
     SeqExec ex{T, reverse};
     ex.chain = chain;
+    if (P.nFronts > 0) ex.lds_buf.assign((size_t)33 * P.max_front_mp + 1024, 0.0);
     if (rmax < 0) {
       spicey_tran_run<K>(ex, P, R, c, g);
     } else {
@@ -106,7 +124,8 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
                                    int64_t *solves_out, int32_t rmax /* <0: v1 interpreter, else v2 with rmax resident slots */) {
   HostProgram hp;
   std::string err;
-  int32_t rc = spicey_build_program(d, hp, err);
+  const int front_cut = reverse >> 8;  // bits 8..: elimination-tree level from which pivots are factored as dense fronts
+  int32_t rc = spicey_build_program(d, hp, err, true, front_cut);
   if (rc != SPICEY_OK) return rc;
   SpiceyProg P = hp.bind(hp.blob.data());
   if (info) {
@@ -137,6 +156,20 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
   std::vector<int32_t> status((size_t)ngroups * 4);
   std::vector<unsigned long long> solves(ngroups);
   R.status = status.data(); R.solves = solves.data();
+  // dense fronts: one workspace per group, the G = 1 schedule (every front on the one emulated workgroup, postorder)
+  std::vector<double> front_ws;
+  std::vector<uint32_t> fs_first, fs_list, fs_owner;
+  std::vector<unsigned int> front_flags;
+  if (P.nFronts > 0) {
+    if (K != 1) return SPICEY_ERR_BAD_DESC;
+    front_ws.assign((size_t)ngroups * (size_t)P.front_ws, 0.0);
+    spicey_build_front_schedule(hp, 1, fs_first, fs_list);
+    fs_owner.assign(P.nFronts, 0u);
+    front_flags.assign((size_t)ngroups * 2 * P.nFronts, 0u);
+    R.front_ws = front_ws.data(); R.fs_first = fs_first.data(); R.fs_list = fs_list.data(); R.fs_owner = fs_owner.data();
+    R.front_flags = front_flags.data();
+    if (info) info->tail_levels = P.nFronts;  // (diagnostic: number of fronts)
+  }
   if (T <= 0 || (T & 63)) return SPICEY_ERR_BAD_DESC;
   if (rmax > 16 || (rmax >= 0 && (!P.has16 || K > 2))) return SPICEY_ERR_BAD_DESC;  // v2 supports K <= 2
   switch (K) {
