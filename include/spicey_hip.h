@@ -93,6 +93,9 @@ typedef struct SpiceyOptions {
                             bit 2 = plain CSR numbering of the L+U entries (no LDS-bank-aware slot-major numbering);
                             bits 8.. = extra empty phases per solve */
   int32_t wgs_per_inst;  /* global-workspace path: workgroups (CUs) cooperating on one instance; 0 auto, 1 = none */
+  int32_t front_cut;     /* dense fronts (large instances): pivots of elimination-tree level >= front_cut are factored as
+                            dense supernodal fronts (LDS-staged panels, MFMA trailing updates) instead of one
+                            barrier-separated level per pivot.  0 = auto (large nonlinear circuits), -1 = never, > 0 = this level */
 } SpiceyOptions;
 
 typedef struct SpiceyInfo {
@@ -116,7 +119,10 @@ typedef struct SpiceyInfo {
   int64_t program_bytes;            /* device-side schedule ("program") size */
   int64_t algorithmic_bytes_solve;  /* SURVEY.md §8(d) formula */
   int32_t factor_reuse;     /* 1: no diodes / switches -> the factors of step 0 are reused, later steps solve only */
-  int32_t reserved0;
+  int32_t n_fronts;         /* dense fronts of the upper elimination tree (0 = none) */
+  int32_t front_cut;        /* first elimination-tree level handled by fronts (0 = none) */
+  int32_t max_front;        /* rows of the largest front (padded to 16) */
+  int64_t front_ws_bytes;   /* front workspace per instance */
 } SpiceyInfo;
 
 typedef struct SpiceyHandle SpiceyHandle;

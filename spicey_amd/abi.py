@@ -37,7 +37,7 @@ class SpiceyDesc(C.Structure):
 
 class SpiceyOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("threads", C.c_int32), ("inst_per_wg", C.c_int32),
-                ("want_currents", C.c_int32), ("force_global", C.c_int32), ("profile", C.c_int32), ("interpreter", C.c_int32), ("geometry", C.c_int32), ("debug", C.c_int32), ("wgs_per_inst", C.c_int32)]
+                ("want_currents", C.c_int32), ("force_global", C.c_int32), ("profile", C.c_int32), ("interpreter", C.c_int32), ("geometry", C.c_int32), ("debug", C.c_int32), ("wgs_per_inst", C.c_int32), ("front_cut", C.c_int32)]
 
 
 class SpiceyInfo(C.Structure):
@@ -46,7 +46,8 @@ class SpiceyInfo(C.Structure):
                 ("n_out", C.c_int32), ("n_workgroups", C.c_int32), ("interpreter", C.c_int32), ("geometry", C.c_int32),
                 ("tail_levels", C.c_int32), ("wgs_per_inst", C.c_int32), ("resident_slots", C.c_int32),
                 ("resident_tasks", C.c_int64), ("streamed_tasks", C.c_int64), ("program_bytes", C.c_int64),
-                ("algorithmic_bytes_solve", C.c_int64), ("factor_reuse", C.c_int32), ("reserved0", C.c_int32)]
+                ("algorithmic_bytes_solve", C.c_int64), ("factor_reuse", C.c_int32), ("n_fronts", C.c_int32),
+                ("front_cut", C.c_int32), ("max_front", C.c_int32), ("front_ws_bytes", C.c_int64)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -64,8 +64,8 @@ struct GpuExec {
   }
 };
 
-template <int K, bool LDS>
-__global__ void __launch_bounds__(1024) spicey_tran_kernel(SpiceyProg P, SpiceyRun R) {
+template <int K, bool LDS, bool FRONTS>
+__global__ void __launch_bounds__(FRONTS ? 512 : 1024) spicey_tran_kernel(SpiceyProg P, SpiceyRun R) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WgCtx<K> c;
   const int wg = (int)blockIdx.x;
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(1024) spicey_tran_kernel(SpiceyProg P, SpiceyR
   // (front scratch behind the workspace / the flags: offsets from `smem` keep the LDS address space)
   const size_t lds_off = LDS ? (((nW + nU + nG) * sizeof(double) + ((size_t)P.nS * K + 4) * sizeof(int32_t) + 15) & ~(size_t)15) : 64;
   GpuExec ex{R.prof ? R.prof + (size_t)wg * SPICEY_PH_SLOTS : nullptr, (double *)(smem + lds_off)};
-  spicey_tran_run<K>(ex, P, R, c, wg);
+  spicey_tran_run<K, FRONTS>(ex, P, R, c, wg);
 }
 
 // Group mode: G workgroups (G CUs) cooperate on ONE large instance whose workspace lives in global memory / L2.
@@ -197,8 +197,8 @@ struct GpuGroupExec {
   }
 };
 
-template <int K>
-__global__ void __launch_bounds__(1024) spicey_tran_kernel_grp(SpiceyProg P, SpiceyRun R) {
+template <int K, bool FRONTS>
+__global__ void __launch_bounds__(FRONTS ? 512 : 1024) spicey_tran_kernel_grp(SpiceyProg P, SpiceyRun R) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // scratch of the dense fronts
   WgCtx<K> c;
   const int G = R.wgs_per_group;
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(1024) spicey_tran_kernel_grp(SpiceyProg P, Spi
     c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
   }
   GpuGroupExec ex{G, wgi, R.grp_sync + (size_t)grp * 4, R.grp_sync + (size_t)grp * 4 + 1, 0u, false, (double *)smem};
-  spicey_tran_run<K>(ex, P, R, c, grp);
+  spicey_tran_run<K, FRONTS>(ex, P, R, c, grp);
 }
 
 // v2: register-resident program (LDS workspace only; 16-bit records)
@@ -325,9 +325,10 @@ hipError_t launch_v2_t(const SpiceyProg &P, const SpiceyResident &Q, const Spice
   return hipGetLastError();
 }
 
-template <int K, bool LDS>
+template <int K, bool LDS, bool FRONTS = false>
 hipError_t launch_t(const SpiceyProg &P, const SpiceyRun &R, int grid, int threads, size_t lds, hipStream_t st) {
-  auto kern = spicey_tran_kernel<K, LDS>;
+  auto kern = spicey_tran_kernel<K, LDS, FRONTS>;
+  if (FRONTS && threads > 512) return hipErrorInvalidValue;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -358,24 +359,35 @@ size_t spicey_gw_doubles_per_wg(const SpiceyProg &P, int K) {
   return ((size_t)P.nW + P.nU + P.nGdyn) * K + (((size_t)P.nS * K + 1) >> 1);
 }
 
+template <int K, bool FRONTS>
+static hipError_t launch_grp_t(const SpiceyProg &P, const SpiceyRun &R, int grid, int threads, size_t lds, hipStream_t st) {
+  auto kern = spicey_tran_kernel_grp<K, FRONTS>;
+  if (FRONTS && threads > 512) return hipErrorInvalidValue;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, R);
+  return hipGetLastError();
+}
+
 hipError_t spicey_launch_tran_grp(const SpiceyProg &P, const SpiceyRun &R, int K, int n_groups, int threads, hipStream_t st) {
   const int grid = n_groups * R.wgs_per_group;
   const size_t lds = spicey_front_lds_bytes(P);
-  if (lds > 48 * 1024) {
-    hipError_t e = K == 1 ? hipFuncSetAttribute(reinterpret_cast<const void *>(spicey_tran_kernel_grp<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                          : hipFuncSetAttribute(reinterpret_cast<const void *>(spicey_tran_kernel_grp<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
+  if (P.nFronts > 0) return K == 1 ? launch_grp_t<1, true>(P, R, grid, threads, lds, st) : hipErrorInvalidValue;
   switch (K) {
-    case 1: hipLaunchKernelGGL(spicey_tran_kernel_grp<1>, dim3(grid), dim3(threads), lds, st, P, R); break;
-    case 2: hipLaunchKernelGGL(spicey_tran_kernel_grp<2>, dim3(grid), dim3(threads), lds, st, P, R); break;
-    default: return hipErrorInvalidValue;
+    case 1: return launch_grp_t<1, false>(P, R, grid, threads, 0, st);
+    case 2: return launch_grp_t<2, false>(P, R, grid, threads, 0, st);
   }
-  return hipGetLastError();
+  return hipErrorInvalidValue;
 }
 
 hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bool lds, int grid, int threads, hipStream_t st) {
   const size_t bytes = spicey_lds_bytes(P, K, lds, 0);
+  if (P.nFronts > 0) {
+    if (K != 1) return hipErrorInvalidValue;
+    return lds ? launch_t<1, true, true>(P, R, grid, threads, bytes, st) : launch_t<1, false, true>(P, R, grid, threads, bytes, st);
+  }
   if (lds) {
     switch (K) {
       case 1: return launch_t<1, true>(P, R, grid, threads, bytes, st);

@@ -24,6 +24,10 @@ struct SpiceyHandle {
   int G = 1;            // workgroups per instance group (group mode: global workspace only)
   unsigned int *d_gsync = nullptr;
   int32_t *d_gflags = nullptr;
+  // dense fronts: workspace [grid][front_ws], schedule of the G workgroups, done flags [grid][2 nFronts]
+  double *d_front_ws = nullptr;
+  uint32_t *d_fs = nullptr;  // first[G + 1] | list[nFronts] | owner[nFronts]
+  unsigned int *d_front_flags = nullptr;
   void *d_res = nullptr;
   SpiceyOptions opt{};
   int n_inst = 0, n_nodes = 0;
@@ -82,7 +86,7 @@ extern "C" void spicey_destroy(SpiceyHandle *h) {
   if (!h) return;
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
   void *ptrs[] = {h->d_res, h->d_blob, h->d_R, h->d_C, h->d_L, h->d_Sron, h->d_Sroff, h->d_Svon, h->d_Svoff, h->d_Dis, h->d_Dn, h->d_Cv,
-                  h->d_Li, h->d_Dv, h->d_Son, h->d_Cv0, h->d_Li0, h->d_Dv0, h->d_Son0, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_gsync, h->d_gflags, h->d_status, h->d_solves, h->d_prof};
+                  h->d_Li, h->d_Dv, h->d_Son, h->d_Cv0, h->d_Li0, h->d_Dv0, h->d_Son0, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_gsync, h->d_gflags, h->d_front_ws, h->d_fs, h->d_front_flags, h->d_status, h->d_solves, h->d_prof};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -123,7 +127,12 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   SpiceyHandle *h = new SpiceyHandle();
   if (opt) h->opt = *opt;
   std::string err;
-  int32_t rc = spicey_build_program(desc, h->hp, err, !((h->opt.debug >> 2) & 1));  // diagnostics: bit 2 = plain CSR numbering
+  // dense fronts: explicit level, or automatic for large nonlinear circuits that run one instance per workgroup (the
+  // interleaved K > 1 layouts and forced interpreter 2 keep the task lists); -1 = never
+  int front_cut = h->opt.front_cut > 0 ? h->opt.front_cut : (h->opt.front_cut == 0 ? -1 : 0);
+  if (h->opt.inst_per_wg > 1 || h->opt.interpreter == 2) front_cut = 0;
+  if (front_cut < 0 && desc && desc->n_inst >= 512) front_cut = 0;  // big batches fill the chip with interleaved instances instead
+  int32_t rc = spicey_build_program(desc, h->hp, err, !((h->opt.debug >> 2) & 1), front_cut);  // diagnostics: bit 2 = plain CSR numbering
   if (rc != SPICEY_OK) {
     g_err = err;
     delete h;
@@ -160,6 +169,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   const bool want_lds = !h->opt.force_global;
   if (K != 0 && K != 1 && K != 2 && K != 4) { h->err = "inst_per_wg must be 0, 1, 2 or 4"; return fail(SPICEY_ERR_BAD_DESC); }
   if (P.nS > 0) K = 1;  // the switch iteration count is per instance: no interleaving
+  if (P.nFronts > 0) K = 1;  // dense fronts: one instance per workgroup (group)
   if (K == 0) {
     // LDS path: one instance per workgroup (measured faster than two interleaved ones: VGPR pressure in phase Z).
     // Global-workspace path (large circuits): once the batch exceeds the CUs, interleaving 2-4 instances shares
@@ -179,6 +189,10 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   if (h->opt.interpreter == 2 && !v2_ok) { h->err = "interpreter 2 needs the LDS workspace, < 65536 workspace entries and inst_per_wg <= 2"; return fail(SPICEY_ERR_BAD_DESC); }
   h->interp = (h->opt.interpreter == 1 || !v2_ok) ? 1 : 2;
   h->T = h->opt.threads > 0 ? h->opt.threads : pick_threads(h->hp, h->interp == 2, K);
+  if (P.nFronts > 0 && h->T > 512) {  // kernels with the dense-front code are built for <= 512 threads (256 VGPRs)
+    if (h->opt.threads > 512) { h->err = "front_cut needs threads <= 512"; return fail(SPICEY_ERR_BAD_DESC); }
+    h->T = 512;
+  }
   if (h->interp == 2 && h->T > spicey_v2_max_threads(K)) { h->err = "interpreter 2 with inst_per_wg = 2 supports at most 256 threads"; return fail(SPICEY_ERR_BAD_DESC); }
   if (h->T > 1024 || (h->T & 63) || h->T < 64) { h->err = "threads must be a multiple of 64 in [64, 1024]"; return fail(SPICEY_ERR_BAD_DESC); }
   h->grid = (h->n_inst + K - 1) / K;
@@ -264,6 +278,19 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
       if ((rc = upload(h, &h->d_gflags, noi, (size_t)h->grid * 4)) != SPICEY_OK) return fail(rc);
     }
   }
+  if (P.nFronts > 0) {
+    std::vector<uint32_t> first, list, owner((size_t)P.nFronts, 0u);
+    spicey_build_front_schedule(h->hp, h->G, first, list);
+    for (int w = 0; w < h->G; w++)
+      for (uint32_t s2 = first[w]; s2 < first[w + 1]; s2++) owner[list[s2]] = (uint32_t)w;
+    std::vector<uint32_t> all(first);
+    all.insert(all.end(), list.begin(), list.end());
+    all.insert(all.end(), owner.begin(), owner.end());
+    if ((rc = upload(h, &h->d_fs, all.data(), all.size())) != SPICEY_OK) return fail(rc);
+    if ((rc = upload(h, &h->d_front_ws, nodbl, (size_t)h->grid * (size_t)P.front_ws)) != SPICEY_OK) return fail(rc);
+    const unsigned int *nou2 = nullptr;
+    if ((rc = upload(h, &h->d_front_flags, nou2, (size_t)h->grid * 2 * (size_t)P.nFronts)) != SPICEY_OK) return fail(rc);
+  }
   const int32_t *noint = nullptr;
   if ((rc = upload(h, &h->d_status, noint, (size_t)h->grid * 4)) != SPICEY_OK) return fail(rc);
   const unsigned long long *noull = nullptr;
@@ -301,6 +328,10 @@ extern "C" int32_t spicey_get_info(SpiceyHandle *h, SpiceyInfo *info) {
   info->program_bytes = (int64_t)h->hp.blob.size();
   info->algorithmic_bytes_solve = h->algo_bytes;
   info->factor_reuse = (h->hp.hdr.nD == 0 && h->hp.hdr.nS == 0 && h->hp.hdr.nDynEnt == 0 && !((h->opt.debug >> 1) & 1)) ? 1 : 0;
+  info->n_fronts = h->hp.hdr.nFronts;
+  info->front_cut = h->hp.hdr.front_cut;
+  info->max_front = h->hp.hdr.max_front_mp;
+  info->front_ws_bytes = h->hp.hdr.front_ws * (int64_t)sizeof(double);
   return SPICEY_OK;
 }
 
@@ -333,6 +364,14 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   R.wgs_per_group = h->G;
   R.grp_sync = h->d_gsync;
   R.grp_flags = h->d_gflags;
+  if (h->hp.hdr.nFronts > 0) {
+    R.front_ws = h->d_front_ws;
+    R.fs_first = h->d_fs;
+    R.fs_list = h->d_fs + (h->G + 1);
+    R.fs_owner = R.fs_list + h->hp.hdr.nFronts;
+    R.front_flags = h->d_front_flags;
+    HIPCHK(h, hipMemsetAsync(h->d_front_flags, 0, (size_t)h->grid * 2 * (size_t)h->hp.hdr.nFronts * sizeof(unsigned int), st));
+  }
   if (h->interp == 2) {
     HIPCHK(h, spicey_launch_tran_v2(h->dprog, h->dres, R, h->K, h->grid, h->T, st, h->packed));
   } else if (h->G > 1) {

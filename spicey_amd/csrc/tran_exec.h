@@ -1160,7 +1160,9 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
 
 // The whole run of one workgroup.  Exec supplies `phase(f)` (run f(tid) for every thread, then
 // barrier) and `threads()`.  All control flow is workgroup-uniform: flags are read after barriers.
-template <int K, class Exec>
+// FRONTS: compile the dense-front sweeps in (their triangular solves keep 16 doubles per thread in registers: kernels
+// built with them are launched with <= 512 threads; the others keep their 1024-thread register budget untouched).
+template <int K, bool FRONTS = false, class Exec>
 SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R, WgCtx<K> &c, int wg) {
   TranPhases<K> ph{P, R, c, ex.threads()};
   TranPhases<K> phl{P, R, c, ex.local_threads()};  // the same phases over ONE workgroup's threads (group mode)
@@ -1177,7 +1179,7 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
   if (c.flags[1]) { code = 1; }
   const bool linear = P.nD == 0 && P.nS == 0 && P.nDynEnt == 0 && !R.no_reuse;  // see spicey_tran_run_v2
   // dense fronts above the cut (K = 1 only; the host enables them for nonlinear circuits, so `linear` is false then)
-  const bool use_fronts = K == 1 && P.nFronts > 0 && R.front_ws != nullptr;
+  const bool use_fronts = FRONTS && K == 1 && P.nFronts > 0 && R.front_ws != nullptr;
   FrontsRun<Exec> fr{ex, P, R, c.W, c.flags, c.inst[0], c.valid[0], use_fronts ? R.front_ws + (size_t)wg * (size_t)P.front_ws : nullptr,
                      use_fronts ? R.front_flags + (size_t)wg * 2 * (size_t)P.nFronts : nullptr, ex.local_threads()};
   unsigned int fepoch = 0;
@@ -1205,7 +1207,7 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
         // (a trailing local run flows straight into the backward chain below, which workgroup 0 runs as well)
         if (local_run && (!ex.serial_chain() || use_fronts)) ex.sync();
       }
-      if (use_fronts) {
+      if constexpr (FRONTS) if (use_fronts) {
         // upper tree: every workgroup sweeps its share of the fronts up, then down (flags between workgroups, no group
         // barrier inside); one group barrier afterwards publishes the upper unknowns to the levels below the cut
         fepoch++;

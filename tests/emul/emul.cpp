@@ -94,7 +94,7 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
     ex.chain = chain;
     if (P.nFronts > 0) ex.lds_buf.assign((size_t)33 * P.max_front_mp + 1024, 0.0);
     if (rmax < 0) {
-      spicey_tran_run<K>(ex, P, R, c, g);
+      spicey_tran_run<K, true>(ex, P, R, c, g);
     } else {
       HostResident hr;
       spicey_build_resident(hp, T, rmax, hr, 24);
@@ -290,5 +290,25 @@ extern "C" int32_t spicey_emul_level_stats(const SpiceyDesc *d, int32_t cap, int
   }
   for (int k = 0; k < hp.hdr.n; k++)
     if (hp.level[k] < cap) pivots[hp.level[k]]++;
+  return SPICEY_OK;
+}
+
+// Front tree introspection (tools/front_stats.py, structural tests): per front k0, p, q, parent, owner under a G-workgroup schedule.
+extern "C" int32_t spicey_emul_front_stats(const SpiceyDesc *d, int32_t front_cut, int32_t G, int32_t cap, int32_t *meta /*[4]: nFronts, cut, maxMp, nLevels*/,
+                                           int64_t *ws_doubles, int32_t *k0, int32_t *p, int32_t *q, int32_t *parent, int32_t *owner, int32_t *seq) {
+  HostProgram hp;
+  std::string err;
+  int32_t rc = spicey_build_program(d, hp, err, true, front_cut);
+  if (rc != SPICEY_OK) return rc;
+  meta[0] = hp.hdr.nFronts; meta[1] = hp.hdr.front_cut; meta[2] = hp.hdr.max_front_mp; meta[3] = hp.hdr.nLevels;
+  *ws_doubles = hp.hdr.front_ws;
+  std::vector<uint32_t> first, list;
+  spicey_build_front_schedule(hp, G, first, list);
+  for (int w = 0; w < G; w++)
+    for (uint32_t s = first[w]; s < first[w + 1]; s++)
+      if ((int)list[s] < cap) { owner[list[s]] = w; seq[list[s]] = (int32_t)(s - first[w]); }
+  for (int f = 0; f < hp.hdr.nFronts && f < cap; f++) {
+    k0[f] = hp.fronts[f].k0; p[f] = hp.fronts[f].p; q[f] = hp.fronts[f].q; parent[f] = hp.fronts[f].parent;
+  }
   return SPICEY_OK;
 }

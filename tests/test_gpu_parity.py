@@ -548,3 +548,53 @@ def test_bench_geometry_512_distinct_diode_chains(oracle_backend):
     # the latency geometry (one 1024-thread workgroup per CU, everything resident) gives the same bits
     lat = HipBackend(geometry=1).run(flat, steps, dt, src)
     assert np.array_equal(lat["out_v"], got["out_v"]) and np.array_equal(lat["out_i"], got["out_i"])
+
+
+def test_dense_fronts_upper_tree(oracle_backend):
+    """Dense fronts (fronts_exec.h): pivots of elimination-tree level >= front_cut are factored as supernodal fronts
+    (LDS panels, lockstep 16 x 16 diagonal blocks, trailing updates), the levels below keep the task lists.  Every cut,
+    workgroup count and workspace placement must give the oracle's answer; for one cut the bits must not depend on G
+    (the front arithmetic has a fixed order, only the task -> thread assignment of the lower levels changes)."""
+    from spicey_amd.lib import HipBackend
+    ckt = parseNetlist(synth.rcd_mesh(34, seed=5, tran=".tran 1e-6 2e-5"))
+    dt, steps = abi.computeEffectiveTimeStep(1e-6, 2e-5)
+    flat = abi.flatten(ckt)
+    src = abi.source_table(ckt, dt, steps)
+    ref = oracle_backend.run(flat, steps, dt, src)
+    for cut in (3, 8, 20):
+        first = None
+        for kw in (dict(force_global=True, wgs_per_inst=1), dict(force_global=True, wgs_per_inst=4), dict(force_global=True, wgs_per_inst=16),
+                   dict(force_global=True, wgs_per_inst=7), dict(interpreter=1)):
+            be = HipBackend(front_cut=cut, **kw)
+            got = be.run(flat, steps, dt, src)
+            assert got["status"] == 0, (cut, kw, got["detail"])
+            assert be.info["n_fronts"] > 0 and be.info["front_cut"] == cut and be.info["threads"] <= 512
+            assert tol_ratio(got["out_v"], ref["out_v"]).max() <= 1.0 and tol_ratio(got["out_i"], ref["out_i"]).max() <= 1.0, (cut, kw)
+            assert np.array_equal(got["iters"], ref["iters"])
+            if first is None:
+                first = got
+            assert np.array_equal(got["out_v"], first["out_v"]) and np.array_equal(got["out_i"], first["out_i"]), (cut, kw)
+    # batch of instances, each with its own group and front workspace; a singular instance is reported, not hidden
+    got3 = HipBackend(front_cut=8, force_global=True, wgs_per_inst=4).run(flat.replicate(3), steps, dt, src)
+    assert got3["status"] == 0 and all(np.array_equal(got3["out_v"][i], got3["out_v"][0]) for i in (1, 2))
+    assert tol_ratio(got3["out_v"][0], ref["out_v"][0]).max() <= 1.0
+    # switches + diodes + inductors through the fronts (iteration counts are data dependent)
+    for name in ("boost_probe", "relay_osc", "half_bridge", "fv_chain"):
+        g = load_golden(name)
+        c2 = parseNetlist(golden_netlist(g))
+        for cut in (1, 2):
+            be = HipBackend(front_cut=cut, interpreter=1)
+            tr = c2.analyses["tran"]
+            dt2, st2 = abi.computeEffectiveTimeStep(tr["dt"], tr["tstop"])
+            f2 = abi.flatten(c2)
+            s2 = abi.source_table(c2, dt2, st2)
+            got = be.run(f2, st2, dt2, s2)
+            r2 = oracle_backend.run(f2, st2, dt2, s2)
+            assert got["status"] == 0 and np.array_equal(got["iters"], r2["iters"]), (name, cut)
+            assert tol_ratio(got["out_v"], r2["out_v"]).max() <= 1.0 and tol_ratio(got["out_i"], r2["out_i"]).max() <= 1.0, (name, cut)
+    # singular through a front: the floating resistor pair of err_singular sits above the cut
+    c3 = parseNetlist(golden_netlist(load_golden("near_sing_d")))
+    tr = c3.analyses["tran"]
+    dt3, st3 = abi.computeEffectiveTimeStep(tr["dt"], tr["tstop"])
+    bad = HipBackend(front_cut=1, interpreter=1).run(abi.flatten(c3), st3, dt3, abi.source_table(c3, dt3, st3))
+    assert bad["status"] == abi.ERR_SINGULAR

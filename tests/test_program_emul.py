@@ -557,3 +557,88 @@ def test_backward_chain_on_one_workgroup_is_bit_identical(name):
         assert a["status"] == b["status"] == 0
         assert np.array_equal(a["out_v"], b["out_v"]) and np.array_equal(a["out_i"], b["out_i"], equal_nan=True)
         assert np.array_equal(a["iters"], b["iters"])
+
+
+# ---- dense fronts of the upper elimination tree (spicey_amd/csrc/fronts_exec.h) ---------------------------------------
+@pytest.mark.parametrize("gen,kw,cuts", [("rcd_mesh", dict(rows=12, seed=5, tran=".tran 1e-6 1e-5"), (1, 2, 4, 8, 16, 31)),
+                                         ("rcd_mesh", dict(rows=34, seed=5, tran=".tran 1e-6 3e-6"), (3, 12)),
+                                         ("diode_chain", dict(n=200, seed=5, tran=".tran 1e-6 1e-5"), (1, 3, 6))])
+def test_dense_fronts_vs_oracle(gen, kw, cuts, oracle_backend):
+    """Pivots of elimination-tree level >= cut leave the task lists and are factored as dense supernodal fronts
+    (assembly from W + children's contribution blocks, blocked LU with 16-pivot panels, interface backward phase).
+    Every cut — from "everything but the leaves" to "the root separator only" — must reproduce the oracle, in both
+    thread orders of every phase (race detector), with several panels per front (rows=34: fronts of > 16 pivots)."""
+    ckt = parseNetlist(getattr(synth, gen)(**kw))
+    tr = ckt.analyses["tran"]
+    dt, steps = abi.computeEffectiveTimeStep(tr["dt"], tr["tstop"])
+    flat, src = abi.flatten(ckt), abi.source_table(ckt, dt, steps)
+    ref = oracle_backend.run(flat, steps, dt, src)
+    for cut in cuts:
+        outs = []
+        for T, rev in ((128, False), (64, True)):
+            be = EmulBackend(1, T, rev, front_cut=cut)
+            got = be.run(flat, steps, dt, src)
+            assert got["status"] == 0 and be.info["tail_levels"] > 0, (cut, got["detail"])  # (tail_levels carries the front count here)
+            assert ratio(got["out_v"], ref["out_v"]).max() <= 1.0 and ratio(got["out_i"], ref["out_i"]).max() <= 1.0, cut
+            assert np.array_equal(got["iters"], ref["iters"])
+            outs.append(got["out_v"])
+        assert np.array_equal(outs[0], outs[1])  # independent of thread count and order
+
+
+def test_dense_fronts_random_circuits_and_errors(oracle_backend):
+    """Fronts for everything above the leaves (cut 1) on the random R/C/L/V/D/S netlists, floating sources included:
+    same status as the oracle (singular included), same iteration counts, parity bar."""
+    from random_circuits import random_netlist
+    for seed in range(60):
+        ckt = parseNetlist(random_netlist(seed, floating_sources=bool(seed & 1)))
+        dt, steps = abi.computeEffectiveTimeStep(ckt.analyses["tran"]["dt"], ckt.analyses["tran"]["tstop"])
+        flat, src = abi.flatten(ckt), abi.source_table(ckt, dt, steps)
+        ref = oracle_backend.run(flat, steps, dt, src)
+        base = EmulBackend(1, 64).run(flat, steps, dt, src)
+        got = EmulBackend(1, 64, True, front_cut=1).run(flat, steps, dt, src)
+        assert got["status"] == ref["status"], seed
+        if ref["status"] or ref["iters"].max() >= 20:
+            continue
+        assert np.array_equal(got["iters"], ref["iters"]), seed
+        scale = max(1.0, float(np.nanmax(np.abs(ref["out_v"]))))
+        tol = 1e-9 * np.abs(ref["out_v"]) + 1e-12 * scale
+        e, eb = (np.abs(got["out_v"] - ref["out_v"]) / tol).max(), (np.abs(base["out_v"] - ref["out_v"]) / tol).max()
+        assert e <= max(1.0, 3.0 * eb), (seed, e, eb)  # (the ill-conditioned seeds are arbitrated in the tests above)
+    for name in ("err_singular", "near_sing_d", "near_sing_f"):
+        flat, steps, dt, src = _inputs(name)
+        got = EmulBackend(1, 64, front_cut=1).run(flat, steps, dt, src)
+        assert got["status"] == abi.ERR_SINGULAR and "step 0 iter 0" in got["detail"]
+
+
+def test_front_schedule_is_a_postorder_partition():
+    """spicey_build_front_schedule: every front on exactly one workgroup; a workgroup's list is in postorder (children
+    before parents: front ids ascend along every root path); a parent's workgroup is the lowest of its subtree."""
+    import ctypes as C
+    from emul import pyemul
+    L = pyemul.lib()
+    i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    L.spicey_emul_front_stats.restype = C.c_int32
+    L.spicey_emul_front_stats.argtypes = [C.POINTER(abi.SpiceyDesc), C.c_int32, C.c_int32, C.c_int32, i32p, i64p] + [i32p] * 6
+    flat = abi.flatten(parseNetlist(synth.rcd_mesh(40, seed=3)))
+    d = flat.desc()
+    for G in (1, 3, 16, 64):
+        cap = 1 << 14
+        meta, ws = np.zeros(4, np.int32), C.c_int64(0)
+        arr = [np.full(cap, -7, np.int32) for _ in range(6)]
+        assert L.spicey_emul_front_stats(C.byref(d), 4, G, cap, meta.ctypes.data_as(i32p), C.byref(ws), *[a.ctypes.data_as(i32p) for a in arr]) == 0
+        nf = int(meta[0])
+        k0, p, q, parent, owner, seq = [a[:nf] for a in arr]
+        assert nf > 20 and (owner >= 0).all() and (owner < G).all() and ws.value > 0
+        for w in range(G):
+            mine = np.nonzero(owner == w)[0]
+            assert sorted(seq[mine]) == list(range(len(mine)))          # a permutation: every front exactly once
+            order = mine[np.argsort(seq[mine])]
+            pos = {int(f): i for i, f in enumerate(order)}
+            for f in order:                                              # children scheduled here come first
+                if parent[f] >= 0 and owner[parent[f]] == w:
+                    assert pos[int(parent[f])] > pos[int(f)]
+        for f in range(nf):
+            if parent[f] >= 0:
+                assert owner[parent[f]] <= owner[f] and parent[f] > f and q[f] > 0
+            else:
+                assert q[f] == 0

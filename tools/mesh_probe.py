@@ -13,23 +13,36 @@ ap.add_argument("--rows", type=int, nargs="+", default=[20, 32, 50])
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--wgs", type=int, nargs="+", default=[0])
+ap.add_argument("--cuts", type=int, nargs="+", default=[0], help="front_cut values: 0 auto, -1 no fronts, > 0 explicit level")
+ap.add_argument("--inst", type=int, default=1)
+ap.add_argument("--profile", action="store_true")
 args = ap.parse_args()
 for rows in args.rows:
     t0 = time.time()
     ckt = parseNetlist(synth.rcd_mesh(rows, seed=3, tran=f".tran 1e-6 {args.steps * 1e-6!r}"))
     steps = args.steps
     flat = abi.flatten(ckt)
+    if args.inst > 1:
+        flat = flat.replicate(args.inst)
     src = abi.source_table(ckt, 1e-6, steps)
     ref = None
-    for G in args.wgs:
+    first_out = None
+    for G, cut in [(g, c) for c in args.cuts for g in args.wgs]:
         t1 = time.time()
-        h = Handle(flat, wgs_per_inst=G)
+        h = Handle(flat, wgs_per_inst=G, front_cut=cut)
         t2 = time.time()
         info = h.info()
         r = h.run(steps, 1e-6, src, want_currents=True)
         rec = dict(rows=rows, n=info["n_var"], nnz_lu=info["nnz_lu"], levels=info["n_levels"], interp=info["interpreter"], T=info["threads"],
                    G=info["wgs_per_inst"], lds=info["lds_bytes"], program_MB=info["program_bytes"] / 1e6, create_s=t2 - t1, status=r["status"],
-                   detail=r.get("detail"), ms_per_step=(r.get("kernel_ms") or 0) / (steps + 1))
+                   detail=r.get("detail"), ms_per_step=(r.get("kernel_ms") or 0) / (steps + 1), fronts=info["n_fronts"], cut=info["front_cut"],
+                   max_front=info["max_front"], front_ws_MB=info["front_ws_bytes"] / 1e6, inst=args.inst)
+        if r["status"] == 0:
+            if first_out is None:
+                first_out = r["out_v"]
+            else:  # against the first configuration of this mesh (e.g. --cuts -1 12: task lists vs fronts)
+                e = np.abs(r["out_v"] - first_out) / (1e-9 * np.abs(first_out) + 1e-12)
+                rec["vs_first_config_over_tol"] = float(e.max())
         if args.check and r["status"] == 0 and info["n_var"] <= 2600:
             if ref is None:
                 from oracle.pyoracle import OracleBackend
