@@ -91,6 +91,7 @@ typedef struct SpiceyOptions {
                             2 = throughput: two 512-thread workgroups per CU (<= 128 VGPRs, wide levels streamed) */
   int32_t debug;         /* diagnostics: bit 0 = no tail merge; bit 1 = refactor every step even for linear circuits;
                             bit 2 = plain CSR numbering of the L+U entries (no LDS-bank-aware slot-major numbering);
+                            bit 3 = dense fronts above 64 rows take the staged (global-memory) path even if they fit LDS;
                             bits 8.. = extra empty phases per solve */
   int32_t wgs_per_inst;  /* global-workspace path: workgroups (CUs) cooperating on one instance; 0 auto, 1 = none */
   int32_t front_cut;     /* dense fronts (large instances): pivots of elimination-tree level >= front_cut are factored as
@@ -180,6 +181,10 @@ void spicey_destroy(SpiceyHandle *h);
  * SpiceyOptions.profile = 1).  out[72]: [0] prologue, [1] B stamp+rhs, [2] S switches, [3] A re-linearise,
  * [4] Z record/next-eval, [8+l] factor level l, [40+l] backward level l.  Returns the slot count. */
 int32_t spicey_debug_phase_cycles(SpiceyHandle *h, uint64_t *out, int32_t n);
+/* The same slots of launched workgroup `wg` (group mode: wg = group * wgs_per_inst + index).  In group mode the slots hold
+ * 100 MHz wall-clock ticks per SECTION of the step: [1] B, [8] factor levels below the front cut, [9] fronts forward,
+ * [10] fronts backward, [11] publish + group barrier, [12..20] inside the fronts, [40] backward levels, [4] Z. */
+int32_t spicey_debug_phase_cycles_wg(SpiceyHandle *h, int32_t wg, uint64_t *out, int32_t n);
 
 /* Library build info: "spicey_hip <abi> gfx950 …" */
 const char *spicey_version(void);

@@ -6,13 +6,18 @@
 // of level >= P.front_cut are taken out of the level-scheduled task lists and factored front by front:
 //
 //   front = supernode (p consecutive pivots with nested row structure = one separator of the nested dissection) plus
-//           its q boundary unknowns, a dense (Mp x ld) block of the per-instance front workspace.
+//           its q boundary unknowns: a dense block, local index i < p pivot k0 + i, [p, Pp) identity padding, Pp + j
+//           boundary element j, column Mp the right-hand side (Pp, Mp multiples of 16).
 //   forward (postorder):  zero -> take the front's own entries + right-hand side over from W (stamped by phase B,
 //           updated in place by the task lists of the levels below the cut) -> add the children's contribution blocks
-//           (extend-add through fr_rel) -> blocked right-looking LU, panels of 16 pivots: panel rows/columns staged
-//           in LDS, 16x16 diagonal block by one wave in lockstep, row / column triangular solves one thread each,
-//           trailing update C -= L U (v_mfma_f64_16x16x4 on the device) -> the trailing (q x q) block + rhs is the
-//           contribution block for the parent.
+//           (extend-add through fr_rel) -> blocked right-looking LU, panels of 16 pivots: the 16 x 16 diagonal block by
+//           ONE wave (registers + cross-lane shuffles), row / column triangular solves one thread each, trailing update
+//           C -= L U in 16 x 16 tiles on v_mfma_f64_16x16x4 -> the trailing (q x q) block + rhs is the contribution
+//           block for the parent.
+//           A front of up to 128 rows lives in LDS for all of this (a CU moves only ~30-60 GB/s to and from L2, and
+//           the right-looking update touches the whole trailing block once per panel); only its U rows (for the
+//           backward solve) and its contribution block go to the front workspace in global memory.  Larger fronts stay
+//           in the workspace and stage one panel at a time through LDS.
 //   backward (reverse postorder): x_B from the ancestors, t = y_P - U_PB x_B, blocked back-substitution, x_P -> W.
 //
 // One workgroup per front; the fronts of a group's G workgroups follow the proportional-mapping schedule of
@@ -21,8 +26,7 @@
 // barrier only.  Every sum has a fixed order that does not depend on G: results are bit-identical for every G.
 #pragma once
 
-#define SPICEY_FB 16     // panel width = MFMA tile edge
-#define SPICEY_LPLD 17   // row stride (doubles) of the L panel in LDS: odd, so that a thread-per-row walk is bank-conflict free
+#include "fronts_exec_consts.h"
 
 template <class Exec>
 struct FrontsRun {
@@ -37,11 +41,14 @@ struct FrontsRun {
   int T;            // threads of ONE workgroup
 
   SPICEY_HD bool foreign(uint32_t f) const { return R.fs_owner[f] != (uint32_t)ex.wg(); }
+  // an LDS-resident front: the block (Mp rows of Mp + 17) plus the 16 x 16 block of L and the reciprocal pivots
+  SPICEY_HD bool fits_lds(const SpiceyFront &F) const {
+    return (size_t)F.Mp * (size_t)(F.Mp + SPICEY_FRONT_LDS_PAD) + 512 <= (size_t)R.front_lds_doubles;
+  }
 
-  // ---- assembly ---------------------------------------------------------------------------------------------
-  SPICEY_HD void assemble(const SpiceyFront &F) const {
-    double *A = FW + F.off;
-    const int nel = F.Mp * F.ld;
+  // ---- assembly into A (row stride lda; LDS or global) ----------------------------------------------------
+  SPICEY_HD void assemble(const SpiceyFront &F, double *A, int lda) const {
+    const int nel = F.Mp * lda;
     ex.wg_phase([&](int t) {
       SPICEY_NOUNROLL
       for (int i = t; i < nel; i += T) A[i] = 0.0;
@@ -49,8 +56,11 @@ struct FrontsRun {
     ex.wg_phase([&](int t) {
       const uint32_t *as = P.fr_asm + (size_t)F.asm0 * 2;
       SPICEY_NOUNROLL
-      for (uint32_t i = (uint32_t)t; i < F.asm_n; i += (uint32_t)T) A[as[2 * i + 1]] = W[as[2 * i]];
-      for (int r = F.p + t; r < F.Pp; r += T) A[(size_t)r * F.ld + r] = 1.0;  // identity padding of the pivot block
+      for (uint32_t i = (uint32_t)t; i < F.asm_n; i += (uint32_t)T) {
+        const uint32_t rc = as[2 * i + 1];  // row << 16 | column
+        A[(size_t)(rc >> 16) * lda + (rc & 0xffffu)] = W[as[2 * i]];
+      }
+      for (int r = F.p + t; r < F.Pp; r += T) A[(size_t)r * lda + r] = 1.0;  // identity padding of the pivot block
     });
     for (uint32_t ci = 0; ci < F.child_n; ci++) {  // extend-add, children in a fixed order
       const SpiceyFront C = P.fr[P.fr_child[F.child0 + ci]];
@@ -60,7 +70,7 @@ struct FrontsRun {
         const int nw = T >> 6, w = t >> 6, lane = t & 63;
         for (int i = w; i < C.q; i += nw) {
           const double *src = Ac + (size_t)(C.Pp + i) * C.ld;
-          double *dst = A + (size_t)rel[i] * F.ld;
+          double *dst = A + (size_t)rel[i] * lda;
           for (int j = lane; j <= C.q; j += 64) {
             const double v = src[j < C.q ? C.Pp + j : C.Mp];
             double *d = dst + (j < C.q ? (int)rel[j] : F.Mp);
@@ -71,21 +81,163 @@ struct FrontsRun {
     }
   }
 
-  // ---- blocked partial LU of the first Pp pivots ------------------------------------------------------------
-  SPICEY_HD void factor(const SpiceyFront &F) const {
+  // ---- 16 x 16 diagonal block of a panel: Up rows (stride su) in place, multipliers -> Ld, reciprocal pivots -> Dinv ----
+  SPICEY_HD void diag_block(double *Up, int su, double *Ld, double *Dinv, int npiv_real) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // wave 0, lane = (row i = lane / 4, column residue jq = lane % 4): the lane's four entries stay in registers for all
+    // 16 elimination steps; the pivot, the row's multiplier source and the pivot row travel by cross-lane shuffles
+    ex.wg_phase([&](int t) {
+      if (t >= 64) return;
+      const int i = t >> 2, jq = t & 3;
+      double a[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) a[m] = Up[(size_t)i * su + jq + 4 * m];
+#pragma unroll
+      for (int k = 0; k < SPICEY_FB; k++) {
+        const double piv = __shfl(a[k >> 2], (k << 2) | (k & 3));
+        const double d = spicey_rcp(piv);
+        const double l = __shfl(a[k >> 2], (t & ~3) | (k & 3)) * d;
+        if (t == 0) {
+          if (fabs(piv) < SPICEY_EPS && k < npiv_real && valid) { flags[1] = 1; flags[2] = inst; }  // solveReal.ts:28
+          Dinv[k] = d;
+        }
+        if (jq == 0 && i > k) Ld[i * SPICEY_FB + k] = l;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const double u = __shfl(a[m], (k << 2) | jq);
+          if (i > k && jq + 4 * m > k) a[m] = fma(-l, u, a[m]);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++) Up[(size_t)i * su + jq + 4 * m] = a[m];
+    });
+#else
+    // the same arithmetic with the block in memory: one wave in lockstep, step k eliminates column k
+    ex.wave_lockstep(64, SPICEY_FB, [&](int lane, int k) {
+      const int i = lane >> 2, jq = lane & 3;
+      const double piv = Up[(size_t)k * su + k];
+      const double d = spicey_rcp(piv);
+      if (lane == 0) {
+        if (fabs(piv) < SPICEY_EPS && k < npiv_real && valid) { flags[1] = 1; flags[2] = inst; }
+        Dinv[k] = d;
+      }
+      if (i > k) {
+        const double l = Up[(size_t)i * su + k] * d;
+        if (jq == 0) Ld[i * SPICEY_FB + k] = l;
+        for (int j = jq; j < SPICEY_FB; j += 4)
+          if (j > k) Up[(size_t)i * su + j] = fma(-l, Up[(size_t)k * su + j], Up[(size_t)i * su + j]);
+      }
+    });
+#endif
+  }
+
+  // ---- triangular solves of a panel: one thread per row of the L panel, one per column of the U panel (rhs included) ----
+  SPICEY_HD void panel_trsm(double *Up, int su, double *Lp, int lpld, const double *Ld, const double *Dinv, int nL, int nU, int t) const {
+    SPICEY_NOUNROLL
+    for (int it = t; it < nL + nU; it += T) {
+      double v[SPICEY_FB];
+      if (it < nL) {
+        double *row = Lp + (size_t)it * lpld;
+        for (int k = 0; k < SPICEY_FB; k++) v[k] = row[k];
+        for (int k = 0; k < SPICEY_FB; k++) {
+          double s = v[k];
+          for (int q2 = 0; q2 < k; q2++) s = fma(-v[q2], Up[(size_t)q2 * su + k], s);
+          v[k] = s * Dinv[k];
+        }
+        for (int k = 0; k < SPICEY_FB; k++) row[k] = v[k];
+      } else {
+        const int c = SPICEY_FB + (it - nL);
+        for (int k = 0; k < SPICEY_FB; k++) v[k] = Up[(size_t)k * su + c];
+        for (int k = 1; k < SPICEY_FB; k++) {
+          double s = v[k];
+          for (int q2 = 0; q2 < k; q2++) s = fma(-Ld[k * SPICEY_FB + q2], v[q2], s);
+          v[k] = s;
+        }
+        for (int k = 1; k < SPICEY_FB; k++) Up[(size_t)k * su + c] = v[k];
+      }
+    }
+  }
+
+  // ---- trailing update C[i][j] -= sum_k Lp[i][k] Up[k][j], i < nrow (multiple of 16), j < ncol ------------------
+  // Device: 16 x 16 tiles, four v_mfma_f64_16x16x4 each (A = -L tile, B = U tile; operand maps: lane l holds A[l & 15][l >> 4]
+  // and B[l >> 4][l & 15], result register r holds C[(l >> 4) + 4 r][l & 15]); the columns up to the next multiple of 16
+  // exist behind C and the U panel (zero padding, left unchanged).  Host: the plain sum, k ascending.
+  SPICEY_HD void trailing(double *C, int ldc, const double *Lp, int lpld, const double *Up, int su, int nrow, int ncol, int t) const {
+    const int nw = T >> 6, w = t >> 6, lane = t & 63;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int tr = nrow >> 4, tc = (ncol + 15) >> 4;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int tile = w; tile < tr * tc; tile += nw) {
+      const int ti = tile / tc, tj = tile - ti * tc;
+      double *c0 = C + (size_t)(ti * 16 + lk) * ldc + tj * 16 + li;
+      d4 acc;
+      acc[0] = c0[0]; acc[1] = c0[(size_t)4 * ldc]; acc[2] = c0[(size_t)8 * ldc]; acc[3] = c0[(size_t)12 * ldc];
+      const double *la = Lp + (size_t)(ti * 16 + li) * lpld + lk;
+      const double *ub = Up + (size_t)lk * su + tj * 16 + li;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[4 * kk], ub[(size_t)4 * kk * su], acc, 0, 0, 0);
+      c0[0] = acc[0]; c0[(size_t)4 * ldc] = acc[1]; c0[(size_t)8 * ldc] = acc[2]; c0[(size_t)12 * ldc] = acc[3];
+    }
+#else
+    const int nchunk = (ncol + 63) >> 6;
+    for (int pr = w; pr < nrow * nchunk; pr += nw) {
+      const int i = pr / nchunk, j = (pr - i * nchunk) * 64 + lane;
+      if (j >= ncol) continue;
+      const double *l = Lp + (size_t)i * lpld;
+      double acc = C[(size_t)i * ldc + j];
+      for (int k = 0; k < SPICEY_FB; k++) acc = fma(-l[k], Up[(size_t)k * su + j], acc);
+      C[(size_t)i * ldc + j] = acc;
+    }
+#endif
+  }
+
+  // ---- blocked partial LU of the first Pp pivots, front resident in LDS (row stride lda = Mp + 17) ----------------
+  SPICEY_HD void factor_lds(const SpiceyFront &F, double *A, int lda, double *scr) const {
+    double *Ld = scr, *Dinv = scr + SPICEY_FB * SPICEY_FB;
+    for (int j0 = 0; j0 < F.Pp; j0 += SPICEY_FB) {
+      const int wU = F.Mp + 1 - j0, nL = F.Mp - j0 - SPICEY_FB;
+      double *Up = A + (size_t)j0 * lda + j0, *Lp = A + (size_t)(j0 + SPICEY_FB) * lda + j0;
+      diag_block(Up, lda, Ld, Dinv, F.p - j0);
+      ex.wg_phase([&](int t) { panel_trsm(Up, lda, Lp, lda, Ld, Dinv, nL, wU - SPICEY_FB, t); });
+      ex.wg_phase([&](int t) {
+        if (t < SPICEY_FB) Up[(size_t)t * lda + t] = Dinv[t];  // reciprocal pivots on the diagonal: what the backward solve reads
+        trailing(Lp + SPICEY_FB, lda, Lp, lda, Up + SPICEY_FB, lda, nL, wU - SPICEY_FB, t);
+      });
+    }
+  }
+  // U rows (backward solve) and contribution block (parent's assembly) of an LDS-resident front -> front workspace
+  SPICEY_HD void store_lds_front(const SpiceyFront &F, const double *A, int lda) const {
+    double *G = FW + F.off;
+    ex.wg_phase([&](int t) {
+      const int nw = T >> 6, w = t >> 6, lane = t & 63;
+      for (int i = w; i < F.p; i += nw)
+        for (int c = lane; c <= F.Mp; c += 64) G[(size_t)i * F.ld + c] = A[(size_t)i * lda + c];
+      for (int i = w; i < F.q; i += nw) {
+        const double *src = A + (size_t)(F.Pp + i) * lda;
+        double *dst = G + (size_t)(F.Pp + i) * F.ld;
+        for (int c = lane; c <= F.q; c += 64) {
+          const int cc = c < F.q ? F.Pp + c : F.Mp;
+          dst[cc] = src[cc];
+        }
+      }
+    });
+  }
+
+  // ---- the same for a front that stays in the workspace: one panel at a time staged through LDS --------------------
+  SPICEY_HD void factor_global(const SpiceyFront &F) const {
     double *A = FW + F.off;
     double *lds = ex.lds();
     for (int j0 = 0; j0 < F.Pp; j0 += SPICEY_FB) {
-      const int su = F.ld - j0;            // row stride of the U panel in LDS
+      const int su = F.ld - j0;            // row stride of the U panel in LDS (the whole padded row: zero columns behind the rhs)
       const int wU = F.Mp + 1 - j0;        // its used width: columns j0 .. Mp (right-hand side) inclusive
       const int nL = F.Mp - j0 - SPICEY_FB;  // rows below the diagonal block
       double *Up = lds, *Ld = Up + (size_t)SPICEY_FB * su, *Dinv = Ld + SPICEY_FB * SPICEY_FB, *Lp = Dinv + SPICEY_FB;
-      // a. panel -> LDS
       ex.wg_phase([&](int t) {
         const int nw = T >> 6, w = t >> 6, lane = t & 63;
         for (int k = w; k < SPICEY_FB; k += nw) {
           const double *src = A + (size_t)(j0 + k) * F.ld + j0;
-          for (int c = lane; c < wU; c += 64) Up[(size_t)k * su + c] = src[c];
+          for (int c = lane; c < su; c += 64) Up[(size_t)k * su + c] = src[c];
         }
         SPICEY_NOUNROLL
         for (int i = t; i < nL * SPICEY_FB; i += T) {
@@ -93,76 +245,27 @@ struct FrontsRun {
           Lp[(size_t)r * SPICEY_LPLD + k] = A[(size_t)(j0 + SPICEY_FB + r) * F.ld + j0 + k];
         }
       });
-      // b. 16 x 16 diagonal block: one wave in lockstep, lane = (row i, column residue jq); step k eliminates column k
-      ex.wave_lockstep(64, SPICEY_FB, [&](int lane, int k) {
-        const int i = lane >> 2, jq = lane & 3;
-        const double piv = Up[(size_t)k * su + k];
-        const double d = spicey_rcp(piv);
-        if (lane == 0) {
-          if (fabs(piv) < SPICEY_EPS && j0 + k < F.p && valid) { flags[1] = 1; flags[2] = inst; }  // solveReal.ts:28
-          Dinv[k] = d;
-        }
-        if (i > k) {
-          const double l = Up[(size_t)i * su + k] * d;
-          if (jq == 0) Ld[i * SPICEY_FB + k] = l;
-          for (int j = jq; j < SPICEY_FB; j += 4)
-            if (j > k) Up[(size_t)i * su + j] = fma(-l, Up[(size_t)k * su + j], Up[(size_t)i * su + j]);
-        }
-      });
-      // c. triangular solves: one thread per row of the L panel, one per column of the U panel (rhs included)
-      ex.wg_phase([&](int t) {
-        const int nU = wU - SPICEY_FB;
-        SPICEY_NOUNROLL
-        for (int it = t; it < nL + nU; it += T) {
-          double v[SPICEY_FB];
-          if (it < nL) {
-            double *row = Lp + (size_t)it * SPICEY_LPLD;
-            for (int k = 0; k < SPICEY_FB; k++) v[k] = row[k];
-            for (int k = 0; k < SPICEY_FB; k++) {
-              double s = v[k];
-              for (int q2 = 0; q2 < k; q2++) s = fma(-v[q2], Up[(size_t)q2 * su + k], s);
-              v[k] = s * Dinv[k];
-            }
-            for (int k = 0; k < SPICEY_FB; k++) row[k] = v[k];
-          } else {
-            const int c = SPICEY_FB + (it - nL);
-            for (int k = 0; k < SPICEY_FB; k++) v[k] = Up[(size_t)k * su + c];
-            for (int k = 1; k < SPICEY_FB; k++) {
-              double s = v[k];
-              for (int q2 = 0; q2 < k; q2++) s = fma(-Ld[k * SPICEY_FB + q2], v[q2], s);
-              v[k] = s;
-            }
-            for (int k = 1; k < SPICEY_FB; k++) Up[(size_t)k * su + c] = v[k];
-          }
-        }
-      });
-      // d. U rows back to the front (reciprocal pivots on the diagonal: what the backward solve reads), trailing update
+      diag_block(Up, su, Ld, Dinv, F.p - j0);
+      ex.wg_phase([&](int t) { panel_trsm(Up, su, Lp, SPICEY_LPLD, Ld, Dinv, nL, wU - SPICEY_FB, t); });
       ex.wg_phase([&](int t) {
         const int nw = T >> 6, w = t >> 6, lane = t & 63;
         for (int k = w; k < SPICEY_FB; k += nw) {
           double *dst = A + (size_t)(j0 + k) * F.ld + j0;
           for (int c = lane; c < wU; c += 64) dst[c] = c == k ? Dinv[k] : Up[(size_t)k * su + c];
         }
-        trailing(A + (size_t)(j0 + SPICEY_FB) * F.ld + j0 + SPICEY_FB, F.ld, Lp, Up + SPICEY_FB, su, nL, wU - SPICEY_FB, t);
+        trailing(A + (size_t)(j0 + SPICEY_FB) * F.ld + j0 + SPICEY_FB, F.ld, Lp, SPICEY_LPLD, Up + SPICEY_FB, su, nL, wU - SPICEY_FB, t);
       });
     }
   }
 
-  // C[i][j] -= sum_k Lp[i][k] Up[k][j], i < nrow, j < ncol (k ascending: the same order on host and device VALU path)
-  SPICEY_HD void trailing(double *C, int ldc, const double *Lp, const double *Up, int su, int nrow, int ncol, int t) const {
-    const int nw = T >> 6, w = t >> 6, lane = t & 63;
-    const int nchunk = (ncol + 63) >> 6;
-    for (int pr = w; pr < nrow * nchunk; pr += nw) {
-      const int i = pr / nchunk, j = (pr - i * nchunk) * 64 + lane;
-      if (j >= ncol) continue;
-      const double *l = Lp + (size_t)i * SPICEY_LPLD;
-      double acc = C[(size_t)i * ldc + j];
-      for (int k = 0; k < SPICEY_FB; k++) acc = fma(-l[k], Up[(size_t)k * su + j], acc);
-      C[(size_t)i * ldc + j] = acc;
+  // ---- backward substitution of one front -----------------------------------------------------------------
+  SPICEY_HD void load_db(const SpiceyFront &F, const double *A, double *Db, int t, int b0) const {
+    // (rows [p, Pp) of the pivot block are identity padding: an LDS-resident front never stores them)
+    for (int e = t; e < SPICEY_FB * SPICEY_FB; e += T) {
+      const int r = b0 + (e >> 4), cc = b0 + (e & 15);
+      Db[e] = r < F.p ? A[(size_t)r * F.ld + cc] : (r == cc ? 1.0 : 0.0);
     }
   }
-
-  // ---- backward substitution of one front -----------------------------------------------------------------
   SPICEY_HD void solve(const SpiceyFront &F) const {
     const double *A = FW + F.off;
     double *lds = ex.lds();
@@ -172,7 +275,7 @@ struct FrontsRun {
       SPICEY_NOUNROLL
       for (int j = t; j < F.q; j += T) xs[F.Pp + j] = W[(size_t)P.nLU + bnd[j]];
       SPICEY_NOUNROLL
-      for (int i = t; i < F.Pp; i += T) tt[i] = A[(size_t)i * F.ld + F.Mp];
+      for (int i = t; i < F.Pp; i += T) tt[i] = i < F.p ? A[(size_t)i * F.ld + F.Mp] : 0.0;
     });
     ex.wg_phase([&](int t) {  // t = y_P - U_PB x_B: four partial sums per row, combined in a fixed order
       SPICEY_NOUNROLL
@@ -188,7 +291,7 @@ struct FrontsRun {
     ex.wg_phase([&](int t) {
       SPICEY_NOUNROLL
       for (int i = t; i < F.p; i += T) tt[i] -= (part[4 * i] + part[4 * i + 1]) + (part[4 * i + 2] + part[4 * i + 3]);
-      for (int e = t; e < SPICEY_FB * SPICEY_FB; e += T) Db[e] = A[(size_t)(b_last + (e >> 4)) * F.ld + b_last + (e & 15)];
+      load_db(F, A, Db, t, b_last);
     });
     for (int b0 = b_last; b0 >= 0; b0 -= SPICEY_FB) {
       // one wave, 16 lanes in lockstep: step s solves x of row k = 15 - s and removes it from the rows above it
@@ -202,14 +305,13 @@ struct FrontsRun {
       if (b0 == 0) break;
       ex.wg_phase([&](int t) {  // rows above the block lose its 16 solved unknowns; next diagonal block -> LDS
         SPICEY_NOUNROLL
-        for (int i = t; i < b0; i += T) {
+        for (int i = t; i < b0 && i < F.p; i += T) {
           const double *row = A + (size_t)i * F.ld + b0;
           double s = tt[i];
           for (int k = 0; k < SPICEY_FB; k++) s = fma(-row[k], xs[b0 + k], s);
           tt[i] = s;
         }
-        const int nb = b0 - SPICEY_FB;  // (the lockstep that read Db has ended with a workgroup barrier)
-        for (int e = t; e < SPICEY_FB * SPICEY_FB; e += T) Db[e] = A[(size_t)(nb + (e >> 4)) * F.ld + nb + (e & 15)];
+        load_db(F, A, Db, t, b0 - SPICEY_FB);  // (the lockstep that read Db has ended with a workgroup barrier)
       });
     }
     ex.wg_phase([&](int t) {
@@ -228,9 +330,24 @@ struct FrontsRun {
         const uint32_t c = P.fr_child[F.child0 + ci];
         if (foreign(c)) ex.front_wait(fl + c, epoch);
       }
-      assemble(F);
-      factor(F);
+      ex.mark(SPICEY_PH_U0 + 4);  // waiting for children of other workgroups
+      if (fits_lds(F)) {
+        double *A = ex.lds();
+        const int lda = F.Mp + SPICEY_FRONT_LDS_PAD;
+        assemble(F, A, lda);
+        ex.mark(SPICEY_PH_U0 + 5);
+        factor_lds(F, A, lda, A + (size_t)F.Mp * lda);
+        ex.mark(SPICEY_PH_U0 + 6);
+        store_lds_front(F, A, lda);
+        ex.mark(SPICEY_PH_U0 + 7);
+      } else {
+        assemble(F, FW + F.off, F.ld);
+        ex.mark(SPICEY_PH_U0 + 8);
+        factor_global(F);
+        ex.mark(SPICEY_PH_U0 + 9);
+      }
       if (F.parent >= 0 && foreign((uint32_t)F.parent)) ex.front_post(fl + f, epoch);
+      ex.mark(SPICEY_PH_U0 + 12);
     }
   }
   SPICEY_HD void backward(unsigned int epoch) const {
@@ -239,7 +356,9 @@ struct FrontsRun {
       const uint32_t f = R.fs_list[s - 1];
       const SpiceyFront F = P.fr[f];
       if (F.parent >= 0 && foreign((uint32_t)F.parent)) ex.front_wait(fl + P.nFronts + F.parent, epoch);
+      ex.mark(SPICEY_PH_U0 + 10);
       solve(F);
+      ex.mark(SPICEY_PH_U0 + 11);
       bool any = false;
       for (uint32_t ci = 0; ci < F.child_n; ci++) any = any || foreign(P.fr_child[F.child0 + ci]);
       if (any) ex.front_post(fl + P.nFronts + f, epoch);

@@ -43,6 +43,7 @@ struct GpuExec {
   __device__ __forceinline__ void wave_lockstep(int nlanes, int nsteps, F f) { gpu_wave_lockstep(nlanes, nsteps, f); }
   __device__ __forceinline__ void front_post(unsigned int *, unsigned int) {}
   __device__ __forceinline__ void front_wait(unsigned int *, unsigned int) {}
+  __device__ __forceinline__ void mark(int) {}
   __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
   __device__ __forceinline__ bool failed() const { return false; }
   __device__ __forceinline__ bool serial_chain() const { return false; }
@@ -109,6 +110,15 @@ struct GpuGroupExec {
   unsigned int epoch;
   bool bad;
   double *lds_;
+  unsigned long long *prof;  // per-workgroup section timers (100 MHz wall ticks since the previous mark), or null
+  unsigned long long last;
+  __device__ __forceinline__ void mark(int slot) {
+    if (prof && threadIdx.x == 0) {
+      const unsigned long long now = (unsigned long long)wall_clock64();
+      prof[slot] += now - last;
+      last = now;
+    }
+  }
   __device__ __forceinline__ int wg() const { return wgi; }
   __device__ __forceinline__ double *lds() const { return lds_; }
   // a phase of THIS workgroup alone (every workgroup of the group runs its own): workgroup barrier only
@@ -217,7 +227,8 @@ __global__ void __launch_bounds__(FRONTS ? 512 : 1024) spicey_tran_kernel_grp(Sp
     c.valid[k] = in < R.n_inst;
     c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
   }
-  GpuGroupExec ex{G, wgi, R.grp_sync + (size_t)grp * 4, R.grp_sync + (size_t)grp * 4 + 1, 0u, false, (double *)smem};
+  GpuGroupExec ex{G, wgi, R.grp_sync + (size_t)grp * 4, R.grp_sync + (size_t)grp * 4 + 1, 0u, false, (double *)smem,
+                  R.prof ? R.prof + (size_t)blockIdx.x * SPICEY_PH_SLOTS : nullptr, (unsigned long long)wall_clock64()};
   spicey_tran_run<K, FRONTS>(ex, P, R, c, grp);
 }
 
@@ -343,7 +354,7 @@ hipError_t launch_t(const SpiceyProg &P, const SpiceyRun &R, int grid, int threa
 // the reciprocal pivots), which also covers the backward solve's vectors
 size_t spicey_front_lds_bytes(const SpiceyProg &P) {
   if (P.nFronts <= 0) return 0;
-  return ((size_t)33 * (size_t)P.max_front_mp + 1024) * sizeof(double);
+  return (size_t)SPICEY_FRONT_LDS_DOUBLES * sizeof(double);  // fronts of up to 128 rows live here whole; larger ones stage panels (max_front_mp <= 448)
 }
 
 size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds, int tail_n) {

@@ -39,7 +39,7 @@ struct SpiceyFront {
   int32_t parent;    // front id or -1
   uint32_t rel0;     // fr_rel[rel0 + j]: local index IN THE PARENT of boundary element j (extend-add map)
   uint32_t off;      // offset (doubles) of the block inside the front workspace
-  uint32_t asm0, asm_n;  // fr_asm[2 (asm0 + t)] = W index, [.. + 1] = local offset row * ld + col: entries the front takes over from W
+  uint32_t asm0, asm_n;  // fr_asm[2 (asm0 + t)] = W index, [.. + 1] = local row << 16 | local column: entries the front takes over from W
   uint32_t bnd0;     // fr_bnd[bnd0 + j]: pivot position of boundary element j
   uint32_t child0, child_n;  // fr_child[child0 + t]: child fronts in assembly order
   uint32_t pad0_, pad1_;
@@ -202,4 +202,5 @@ struct SpiceyRun {
   double *front_ws;
   const uint32_t *fs_first, *fs_list, *fs_owner;  // fs_owner[nFronts]: workgroup (of the group) that runs a front
   unsigned int *front_flags;
+  int32_t front_lds_doubles;  // LDS scratch per workgroup (fronts that fit live there whole; tests shrink it to force the staged path)
 };

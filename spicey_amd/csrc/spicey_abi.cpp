@@ -13,6 +13,7 @@
 #include "../../include/spicey_hip.h"
 #include "kernels.h"
 #include "symbolic.h"
+#include "fronts_exec_consts.h"
 
 struct SpiceyHandle {
   HostProgram hp;
@@ -296,7 +297,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   const unsigned long long *noull = nullptr;
   if ((rc = upload(h, &h->d_solves, noull, (size_t)h->grid)) != SPICEY_OK) return fail(rc);
   if (h->opt.profile)
-    if ((rc = upload(h, &h->d_prof, noull, (size_t)h->grid * 72)) != SPICEY_OK) return fail(rc);
+    if ((rc = upload(h, &h->d_prof, noull, (size_t)h->grid * h->G * 72)) != SPICEY_OK) return fail(rc);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     h->err = "stream/event creation failed";
     return fail(SPICEY_ERR_HIP);
@@ -359,7 +360,7 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   R.gstat = h->d_gstat; R.statv = h->d_statv; R.rcoef = h->d_rcoef; R.gW = h->d_gW; R.dpar = h->d_dpar;
   R.src = d_src_table; R.out_v = d_out_v; R.out_i = d_out_i; R.iters = d_iters;
   R.status = h->d_status; R.solves = h->d_solves; R.prof = h->d_prof;
-  if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, (size_t)h->grid * 72 * sizeof(unsigned long long), st));
+  if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, (size_t)h->grid * h->G * 72 * sizeof(unsigned long long), st));
   HIPCHK(h, hipEventRecord(h->ev0, st));
   R.wgs_per_group = h->G;
   R.grp_sync = h->d_gsync;
@@ -370,6 +371,7 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
     R.fs_list = h->d_fs + (h->G + 1);
     R.fs_owner = R.fs_list + h->hp.hdr.nFronts;
     R.front_flags = h->d_front_flags;
+    R.front_lds_doubles = (h->opt.debug & 8) ? 6144 : SPICEY_FRONT_LDS_DOUBLES;  // diagnostics: bit 3 = stage every front above 64 rows through panels
     HIPCHK(h, hipMemsetAsync(h->d_front_flags, 0, (size_t)h->grid * 2 * (size_t)h->hp.hdr.nFronts * sizeof(unsigned int), st));
   }
   if (h->interp == 2) {
@@ -515,6 +517,21 @@ extern "C" int32_t spicey_debug_phase_cycles(SpiceyHandle *h, uint64_t *out, int
   if (spicey_sync(h) == SPICEY_ERR_HIP) return 0;
   unsigned long long tmp[72];
   if (hipMemcpy(tmp, h->d_prof, sizeof(tmp), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  for (int i = 0; i < n && i < 72; i++) out[i] = tmp[i];
+  return 72;
+}
+
+// Same for launched workgroup `wg` (group mode: wg = group * wgs_per_inst + index; the slots then hold 100 MHz wall ticks
+// per SECTION: [1] B, [8] factor levels below the cut, [9] fronts forward, [10] fronts backward, [11] sync + publish,
+// [12..20] inside the fronts (wait, assemble, panel load, diagonal block, triangular solves, trailing update, ...), [40] backward
+// levels, [4] Z).
+extern "C" int32_t spicey_debug_phase_cycles_wg(SpiceyHandle *h, int32_t wg, uint64_t *out, int32_t n) {
+  if (!h || !out) return 0;
+  for (int i = 0; i < n; i++) out[i] = 0;
+  if (!h->d_prof || wg < 0 || wg >= h->grid * h->G) return 0;
+  if (spicey_sync(h) == SPICEY_ERR_HIP) return 0;
+  unsigned long long tmp[72];
+  if (hipMemcpy(tmp, h->d_prof + (size_t)wg * 72, sizeof(tmp), hipMemcpyDeviceToHost) != hipSuccess) return 0;
   for (int i = 0; i < n && i < 72; i++) out[i] = tmp[i];
   return 72;
 }

@@ -724,13 +724,13 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
       double work = 0;
       for (int i = 0; i < f.p; i++) {
         const int k = f.k0 + i;
-        hp.fr_asm.push_back((uint32_t)diag[k]); hp.fr_asm.push_back((uint32_t)(i * f.ld + i));
+        hp.fr_asm.push_back((uint32_t)diag[k]); hp.fr_asm.push_back(((uint32_t)i << 16) | (uint32_t)i);  // row << 16 | column
         for (int b : upper[k]) {
           const int lb = loc(b);
-          hp.fr_asm.push_back((uint32_t)E.find(k, b)); hp.fr_asm.push_back((uint32_t)(i * f.ld + lb));
-          hp.fr_asm.push_back((uint32_t)E.find(b, k)); hp.fr_asm.push_back((uint32_t)(lb * f.ld + i));
+          hp.fr_asm.push_back((uint32_t)E.find(k, b)); hp.fr_asm.push_back(((uint32_t)i << 16) | (uint32_t)lb);
+          hp.fr_asm.push_back((uint32_t)E.find(b, k)); hp.fr_asm.push_back(((uint32_t)lb << 16) | (uint32_t)i);
         }
-        hp.fr_asm.push_back((uint32_t)(nLU + k)); hp.fr_asm.push_back((uint32_t)(i * f.ld + f.Mp));
+        hp.fr_asm.push_back((uint32_t)(nLU + k)); hp.fr_asm.push_back(((uint32_t)i << 16) | (uint32_t)f.Mp);
         work += (double)upper[k].size() * (double)(upper[k].size() + 1);
       }
       f.asm_n = (uint32_t)(hp.fr_asm.size() / 2) - f.asm0;

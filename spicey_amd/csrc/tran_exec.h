@@ -1188,6 +1188,7 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
     int iter = 0;
     for (;;) {
       ex.phase(SPICEY_PH_B, [&](int tid) { ph.b_stamp(tid); });
+      ex.mark(SPICEY_PH_B);
       {
         // Group mode: runs of narrow factor levels (<= 1024 tasks, one per thread: the last pivots of the top separator) also go to
         // workgroup 0 alone; a group barrier separates such a run from the next level that everybody works on.
@@ -1207,14 +1208,18 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
         // (a trailing local run flows straight into the backward chain below, which workgroup 0 runs as well)
         if (local_run && (!ex.serial_chain() || use_fronts)) ex.sync();
       }
+      ex.mark(SPICEY_PH_U0);
       if constexpr (FRONTS) if (use_fronts) {
         // upper tree: every workgroup sweeps its share of the fronts up, then down (flags between workgroups, no group
         // barrier inside); one group barrier afterwards publishes the upper unknowns to the levels below the cut
         fepoch++;
         fr.forward(fepoch);
+        ex.mark(SPICEY_PH_U0 + 1);
         fr.backward(fepoch);
+        ex.mark(SPICEY_PH_U0 + 2);
         ex.local_phase([&](int tid) { if (tid == 0) c.W[(size_t)P.one_slot * K] = 1.0; });
         ex.sync();
+        ex.mark(SPICEY_PH_U0 + 3);
       }
       if (ex.serial_chain()) {
         // Group mode: the backward levels carry little work (mesh 100^2: 172 k products over 297 levels) but each
@@ -1236,6 +1241,7 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
         }
       }
       ex.phase(SPICEY_PH_K0, [&](int tid) { ph.k_scale(tid); });
+      ex.mark(SPICEY_PH_K0);
       // a cross-workgroup barrier that timed out inside this iteration leaves a partially computed workspace: nothing of
       // it may be recorded or reported as a success (group mode only; the flag is sticky and uniform across the group)
       if (ex.failed()) { code = 3; err_step = step; err_iter = iter; break; }
@@ -1259,6 +1265,7 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
           if (c.valid[k]) R.iters[(size_t)c.inst[k] * (size_t)(R.steps + 1) + (size_t)step] = iter + 1;
       ph.z_record(tid, step, linear);
     });
+    ex.mark(SPICEY_PH_Z);
     if (ex.failed()) { code = 3; err_step = step; break; }  // also covers the last step and runs with steps = 0
   }
   ex.phase(SPICEY_PH_PRO, [&](int tid) {

@@ -21,7 +21,7 @@ _LIB = None
 EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "spicey_get_state", "spicey_set_state", "spicey_reset_state",
            "spicey_last_solve_count",
            "spicey_last_kernel_ms", "spicey_get_info", "spicey_last_error", "spicey_destroy", "spicey_version",
-           "spicey_debug_phase_cycles",
+           "spicey_debug_phase_cycles", "spicey_debug_phase_cycles_wg",
            "spicey_ac_create", "spicey_ac_run", "spicey_ac_get_info", "spicey_ac_last_kernel_ms", "spicey_ac_last_error", "spicey_ac_destroy",
            "spicey_format_tran", "spicey_to_precision6"]
 
@@ -66,6 +66,8 @@ def load():
     L.spicey_version.restype = C.c_char_p
     L.spicey_debug_phase_cycles.restype = C.c_int32
     L.spicey_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32]
+    L.spicey_debug_phase_cycles_wg.restype = C.c_int32
+    L.spicey_debug_phase_cycles_wg.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.c_int32]
     L.spicey_ac_create.restype = C.c_int32
     L.spicey_ac_create.argtypes = [C.POINTER(abi.SpiceyDesc), C.POINTER(abi.SpiceyOptions), C.POINTER(vp)]
     L.spicey_ac_run.restype = C.c_int32
@@ -95,7 +97,7 @@ class Handle:
 
     def __init__(self, flat: abi.FlatCircuit, device: int = 0, threads: int = 0, inst_per_wg: int = 0,
                  force_global: bool = False, profile: bool = False, interpreter: int = 0, geometry: int = 0, no_tail: bool = False, debug_empty_phases: int = 0, wgs_per_inst: int = 0,
-                 no_reuse: bool = False, csr_numbering: bool = False, front_cut: int = 0):
+                 no_reuse: bool = False, csr_numbering: bool = False, front_cut: int = 0, stage_fronts: bool = False):
         self.L = load()
         self.flat = flat
         opt = abi.SpiceyOptions()
@@ -105,7 +107,7 @@ class Handle:
         opt.geometry = int(geometry)
         opt.wgs_per_inst = int(wgs_per_inst)
         opt.front_cut = int(front_cut)
-        opt.debug = (1 if no_tail else 0) | (2 if no_reuse else 0) | (4 if csr_numbering else 0) | (int(debug_empty_phases) << 8)
+        opt.debug = (1 if no_tail else 0) | (2 if no_reuse else 0) | (4 if csr_numbering else 0) | (8 if stage_fronts else 0) | (int(debug_empty_phases) << 8)
         d = flat.desc()
         hp = C.c_void_p()
         rc = self.L.spicey_create(C.byref(d), C.byref(opt), C.byref(hp))
@@ -162,6 +164,12 @@ class Handle:
         a = list(buf)
         return {"prologue": a[0], "B": a[1], "S": a[2], "A": a[3], "Z": a[4], "run_cycles": a[5], "run_wall_ticks_100MHz": a[6],
                 "U": a[8:40], "K": a[40:72]}
+
+    def section_ticks(self, wg: int) -> list:
+        """Group mode, profile=True: 100 MHz wall ticks per section of launched workgroup `wg` (see spicey_hip.h)."""
+        buf = (C.c_uint64 * 72)()
+        self.L.spicey_debug_phase_cycles_wg(self.h, int(wg), buf, 72)
+        return list(buf)
 
     def state(self) -> dict:
         f = self.flat
@@ -274,9 +282,9 @@ class HipBackend:
     """Backend interface used by spicey_amd.simulate: one handle per call (the reference API is stateless)."""
 
     def __init__(self, device: int = 0, threads: int = 0, inst_per_wg: int = 0, force_global: bool = False, interpreter: int = 0,
-                 geometry: int = 0, wgs_per_inst: int = 0, no_reuse: bool = False, front_cut: int = 0):
+                 geometry: int = 0, wgs_per_inst: int = 0, no_reuse: bool = False, front_cut: int = 0, stage_fronts: bool = False):
         self.kw = dict(device=device, threads=threads, inst_per_wg=inst_per_wg, force_global=force_global, interpreter=interpreter,
-                       geometry=geometry, wgs_per_inst=wgs_per_inst, no_reuse=no_reuse, front_cut=front_cut)
+                       geometry=geometry, wgs_per_inst=wgs_per_inst, no_reuse=no_reuse, front_cut=front_cut, stage_fronts=stage_fronts)
         self.info: Optional[dict] = None
 
     def run(self, flat: abi.FlatCircuit, steps: int, dt: float, src: np.ndarray, want_currents: bool = True,

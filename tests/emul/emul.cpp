@@ -43,6 +43,7 @@ struct SeqExec {
   }
   void front_post(unsigned int *, unsigned int) {}
   void front_wait(unsigned int *, unsigned int) {}
+  void mark(int) {}
   int local_threads() const { return chain ? T / 2 : T; }
   void sync() {}
   template <class F>
@@ -92,7 +93,7 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
     }
     SeqExec ex{T, reverse};
     ex.chain = chain;
-    if (P.nFronts > 0) ex.lds_buf.assign((size_t)33 * P.max_front_mp + 1024, 0.0);
+    if (P.nFronts > 0) ex.lds_buf.assign((size_t)SPICEY_FRONT_LDS_DOUBLES, 0.0);
     if (rmax < 0) {
       spicey_tran_run<K, true>(ex, P, R, c, g);
     } else {
@@ -168,6 +169,7 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
     front_flags.assign((size_t)ngroups * 2 * P.nFronts, 0u);
     R.front_ws = front_ws.data(); R.fs_first = fs_first.data(); R.fs_list = fs_list.data(); R.fs_owner = fs_owner.data();
     R.front_flags = front_flags.data();
+    R.front_lds_doubles = (reverse & 8) ? 6144 : SPICEY_FRONT_LDS_DOUBLES;  // bit 3: force the staged path for fronts above 64 rows
     if (info) info->tail_levels = P.nFronts;  // (diagnostic: number of fronts)
   }
   if (T <= 0 || (T & 63)) return SPICEY_ERR_BAD_DESC;

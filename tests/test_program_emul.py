@@ -575,14 +575,14 @@ def test_dense_fronts_vs_oracle(gen, kw, cuts, oracle_backend):
     ref = oracle_backend.run(flat, steps, dt, src)
     for cut in cuts:
         outs = []
-        for T, rev in ((128, False), (64, True)):
-            be = EmulBackend(1, T, rev, front_cut=cut)
+        for T, rev, stage in ((128, False, False), (64, True, False), (128, True, True)):  # stage: fronts above 64 rows through LDS panels
+            be = EmulBackend(1, T, rev, front_cut=cut, stage_fronts=stage)
             got = be.run(flat, steps, dt, src)
             assert got["status"] == 0 and be.info["tail_levels"] > 0, (cut, got["detail"])  # (tail_levels carries the front count here)
             assert ratio(got["out_v"], ref["out_v"]).max() <= 1.0 and ratio(got["out_i"], ref["out_i"]).max() <= 1.0, cut
             assert np.array_equal(got["iters"], ref["iters"])
             outs.append(got["out_v"])
-        assert np.array_equal(outs[0], outs[1])  # independent of thread count and order
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])  # independent of thread count, order, front placement
 
 
 def test_dense_fronts_random_circuits_and_errors(oracle_backend):

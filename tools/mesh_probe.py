@@ -29,7 +29,7 @@ for rows in args.rows:
     first_out = None
     for G, cut in [(g, c) for c in args.cuts for g in args.wgs]:
         t1 = time.time()
-        h = Handle(flat, wgs_per_inst=G, front_cut=cut)
+        h = Handle(flat, wgs_per_inst=G, front_cut=cut, profile=args.profile)
         t2 = time.time()
         info = h.info()
         r = h.run(steps, 1e-6, src, want_currents=True)
@@ -51,4 +51,11 @@ for rows in args.rows:
             e = np.abs(r["out_v"][:, : ref["out_v"].shape[1]] - ref["out_v"]) / (1e-9 * np.abs(ref["out_v"]) + 1e-12)
             rec["err_over_tol"] = float(e.max())
         print(json.dumps(rec), flush=True)
+        if args.profile and r["status"] == 0:
+            names = {1: "B", 8: "factor<cut", 9: "fronts_fwd", 10: "fronts_bwd", 11: "publish+sync", 40: "backward", 4: "Z",
+                     12: "f.wait", 13: "f.assemble", 14: "f.panel_load", 15: "f.diag", 16: "f.trsm", 17: "f.trail+wb", 18: "b.wait", 19: "b.solve", 20: "f.post"}
+            for wgi in range(info["wgs_per_inst"]):
+                tk = h.section_ticks(wgi)
+                per = {names[k]: round(tk[k] * 10.0 / 1000.0 / (steps + 1), 1) for k in names}  # us per step
+                print(f"  wg {wgi:2d} us/step:", per, flush=True)
         h.close()
