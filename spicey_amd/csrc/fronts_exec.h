@@ -54,27 +54,53 @@ struct FrontsRun {
       for (int i = t; i < nel; i += T) A[i] = 0.0;
     });
     ex.wg_phase([&](int t) {
+      // gathers in batches of four: the index loads, then the four dependent W loads, are in flight together (one
+      // dependent round trip to L2 per batch instead of per entry)
       const uint32_t *as = P.fr_asm + (size_t)F.asm0 * 2;
       SPICEY_NOUNROLL
-      for (uint32_t i = (uint32_t)t; i < F.asm_n; i += (uint32_t)T) {
-        const uint32_t rc = as[2 * i + 1];  // row << 16 | column
-        A[(size_t)(rc >> 16) * lda + (rc & 0xffffu)] = W[as[2 * i]];
+      for (uint32_t i0 = (uint32_t)t; i0 < F.asm_n; i0 += 4u * (uint32_t)T) {
+        uint32_t id[4], rc[4];
+        double v[4];
+        SPICEY_UNROLL
+        for (int b = 0; b < 4; b++) {
+          const uint32_t i = i0 + (uint32_t)b * (uint32_t)T;
+          const bool have = i < F.asm_n;
+          id[b] = have ? as[2 * i] : as[2 * i0];
+          rc[b] = have ? as[2 * i + 1] : 0xffffffffu;
+        }
+        SPICEY_UNROLL
+        for (int b = 0; b < 4; b++) v[b] = W[id[b]];
+        SPICEY_UNROLL
+        for (int b = 0; b < 4; b++)
+          if (rc[b] != 0xffffffffu) A[(size_t)(rc[b] >> 16) * lda + (rc[b] & 0xffffu)] = v[b];
       }
       for (int r = F.p + t; r < F.Pp; r += T) A[(size_t)r * lda + r] = 1.0;  // identity padding of the pivot block
     });
+    ex.mark(SPICEY_PH_U0 + 17);
     for (uint32_t ci = 0; ci < F.child_n; ci++) {  // extend-add, children in a fixed order
       const SpiceyFront C = P.fr[P.fr_child[F.child0 + ci]];
       const double *Ac = FW + C.off;
       const uint32_t *rel = P.fr_rel + C.rel0;
       ex.wg_phase([&](int t) {
+        // a wave takes four rows of the contribution block at a time: their loads are issued together
         const int nw = T >> 6, w = t >> 6, lane = t & 63;
-        for (int i = w; i < C.q; i += nw) {
-          const double *src = Ac + (size_t)(C.Pp + i) * C.ld;
-          double *dst = A + (size_t)rel[i] * lda;
+        for (int i0 = w * 4; i0 < C.q; i0 += nw * 4) {
           for (int j = lane; j <= C.q; j += 64) {
-            const double v = src[j < C.q ? C.Pp + j : C.Mp];
-            double *d = dst + (j < C.q ? (int)rel[j] : F.Mp);
-            *d += v;
+            const int sc = j < C.q ? C.Pp + j : C.Mp, dc = j < C.q ? (int)rel[j] : F.Mp;
+            double v[4];
+            uint32_t rr[4];
+            SPICEY_UNROLL
+            for (int b = 0; b < 4; b++) {
+              const int i = i0 + b < C.q ? i0 + b : i0;
+              v[b] = Ac[(size_t)(C.Pp + i) * C.ld + sc];
+              rr[b] = rel[i];
+            }
+            double o[4];
+            SPICEY_UNROLL
+            for (int b = 0; b < 4; b++) o[b] = A[(size_t)rr[b] * lda + dc];
+            SPICEY_UNROLL
+            for (int b = 0; b < 4; b++)
+              if (i0 + b < C.q) A[(size_t)rr[b] * lda + dc] = o[b] + v[b];
           }
         }
       });
@@ -138,21 +164,28 @@ struct FrontsRun {
       double v[SPICEY_FB];
       if (it < nL) {
         double *row = Lp + (size_t)it * lpld;
+        SPICEY_UNROLL
         for (int k = 0; k < SPICEY_FB; k++) v[k] = row[k];
+        // right-looking: l_k = v_k / u_kk, then the 15 - k later entries lose l_k u_kj — independent of each other, so the
+        // dependent chain is 16 steps instead of the 120 of a left-looking dot product per entry (same operations, same order per entry)
+        SPICEY_UNROLL
         for (int k = 0; k < SPICEY_FB; k++) {
-          double s = v[k];
-          for (int q2 = 0; q2 < k; q2++) s = fma(-v[q2], Up[(size_t)q2 * su + k], s);
-          v[k] = s * Dinv[k];
+          v[k] *= Dinv[k];
+          SPICEY_UNROLL
+          for (int j = k + 1; j < SPICEY_FB; j++) v[j] = fma(-v[k], Up[(size_t)k * su + j], v[j]);
         }
+        SPICEY_UNROLL
         for (int k = 0; k < SPICEY_FB; k++) row[k] = v[k];
       } else {
         const int c = SPICEY_FB + (it - nL);
+        SPICEY_UNROLL
         for (int k = 0; k < SPICEY_FB; k++) v[k] = Up[(size_t)k * su + c];
-        for (int k = 1; k < SPICEY_FB; k++) {
-          double s = v[k];
-          for (int q2 = 0; q2 < k; q2++) s = fma(-Ld[k * SPICEY_FB + q2], v[q2], s);
-          v[k] = s;
+        SPICEY_UNROLL
+        for (int k = 0; k < SPICEY_FB - 1; k++) {
+          SPICEY_UNROLL
+          for (int i2 = k + 1; i2 < SPICEY_FB; i2++) v[i2] = fma(-Ld[i2 * SPICEY_FB + k], v[k], v[i2]);
         }
+        SPICEY_UNROLL
         for (int k = 1; k < SPICEY_FB; k++) Up[(size_t)k * su + c] = v[k];
       }
     }
@@ -168,16 +201,32 @@ struct FrontsRun {
     typedef double d4 __attribute__((ext_vector_type(4)));
     const int tr = nrow >> 4, tc = (ncol + 15) >> 4;
     const int li = lane & 15, lk = lane >> 4;
-    for (int tile = w; tile < tr * tc; tile += nw) {
-      const int ti = tile / tc, tj = tile - ti * tc;
-      double *c0 = C + (size_t)(ti * 16 + lk) * ldc + tj * 16 + li;
-      d4 acc;
-      acc[0] = c0[0]; acc[1] = c0[(size_t)4 * ldc]; acc[2] = c0[(size_t)8 * ldc]; acc[3] = c0[(size_t)12 * ldc];
-      const double *la = Lp + (size_t)(ti * 16 + li) * lpld + lk;
-      const double *ub = Up + (size_t)lk * su + tj * 16 + li;
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[4 * kk], ub[(size_t)4 * kk * su], acc, 0, 0, 0);
-      c0[0] = acc[0]; c0[(size_t)4 * ldc] = acc[1]; c0[(size_t)8 * ldc] = acc[2]; c0[(size_t)12 * ldc] = acc[3];
+    // four tiles per turn: their sixteen C loads are in flight together before the first MFMA needs one
+    for (int tile0 = w; tile0 < tr * tc; tile0 += 4 * nw) {
+      double *c0[4];
+      d4 acc[4];
+      bool have[4];
+      SPICEY_UNROLL
+      for (int b = 0; b < 4; b++) {
+        const int tile = tile0 + b * nw;
+        have[b] = tile < tr * tc;
+        const int tl = have[b] ? tile : tile0;
+        const int ti = tl / tc, tj = tl - ti * tc;
+        c0[b] = C + (size_t)(ti * 16 + lk) * ldc + tj * 16 + li;
+        acc[b][0] = c0[b][0]; acc[b][1] = c0[b][(size_t)4 * ldc]; acc[b][2] = c0[b][(size_t)8 * ldc]; acc[b][3] = c0[b][(size_t)12 * ldc];
+      }
+      SPICEY_UNROLL
+      for (int b = 0; b < 4; b++) {
+        const int tile = have[b] ? tile0 + b * nw : tile0;
+        const int ti = tile / tc, tj = tile - ti * tc;
+        const double *la = Lp + (size_t)(ti * 16 + li) * lpld + lk;
+        const double *ub = Up + (size_t)lk * su + tj * 16 + li;
+        SPICEY_UNROLL
+        for (int kk = 0; kk < 4; kk++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[4 * kk], ub[(size_t)4 * kk * su], acc[b], 0, 0, 0);
+      }
+      SPICEY_UNROLL
+      for (int b = 0; b < 4; b++)
+        if (have[b]) { c0[b][0] = acc[b][0]; c0[b][(size_t)4 * ldc] = acc[b][1]; c0[b][(size_t)8 * ldc] = acc[b][2]; c0[b][(size_t)12 * ldc] = acc[b][3]; }
     }
 #else
     const int nchunk = (ncol + 63) >> 6;
@@ -198,12 +247,16 @@ struct FrontsRun {
     for (int j0 = 0; j0 < F.Pp; j0 += SPICEY_FB) {
       const int wU = F.Mp + 1 - j0, nL = F.Mp - j0 - SPICEY_FB;
       double *Up = A + (size_t)j0 * lda + j0, *Lp = A + (size_t)(j0 + SPICEY_FB) * lda + j0;
+      ex.mark(SPICEY_PH_U0 + 13);
       diag_block(Up, lda, Ld, Dinv, F.p - j0);
+      ex.mark(SPICEY_PH_U0 + 14);
       ex.wg_phase([&](int t) { panel_trsm(Up, lda, Lp, lda, Ld, Dinv, nL, wU - SPICEY_FB, t); });
+      ex.mark(SPICEY_PH_U0 + 15);
       ex.wg_phase([&](int t) {
         if (t < SPICEY_FB) Up[(size_t)t * lda + t] = Dinv[t];  // reciprocal pivots on the diagonal: what the backward solve reads
         trailing(Lp + SPICEY_FB, lda, Lp, lda, Up + SPICEY_FB, lda, nL, wU - SPICEY_FB, t);
       });
+      ex.mark(SPICEY_PH_U0 + 16);
     }
   }
   // U rows (backward solve) and contribution block (parent's assembly) of an LDS-resident front -> front workspace
@@ -283,7 +336,12 @@ struct FrontsRun {
         const int i = it >> 2, sg = it & 3;
         const double *row = A + (size_t)i * F.ld + F.Pp;
         double s = 0.0;
-        for (int j = sg; j < F.q; j += 4) s = fma(row[j], xs[F.Pp + j], s);
+        int j = sg;
+        for (; j + 12 < F.q; j += 16) {  // four loads in flight; the sum keeps its order
+          const double r0 = row[j], r1 = row[j + 4], r2 = row[j + 8], r3 = row[j + 12];
+          s = fma(r0, xs[F.Pp + j], s); s = fma(r1, xs[F.Pp + j + 4], s); s = fma(r2, xs[F.Pp + j + 8], s); s = fma(r3, xs[F.Pp + j + 12], s);
+        }
+        for (; j < F.q; j += 4) s = fma(row[j], xs[F.Pp + j], s);
         part[it] = s;
       }
     });

@@ -264,11 +264,14 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
     // group mode: several CUs per instance when the batch leaves CUs idle and the circuit is large enough for the
     // cross-workgroup barrier (~3 us per phase) to pay; all workgroups must be co-resident: grid * G <= #CU
     int G = h->opt.wgs_per_inst;
-    if (G < 0 || G > 64 || (G > 1 && K > 2)) { h->err = "wgs_per_inst must be in [0, 64] (and inst_per_wg <= 2 with it)"; return fail(SPICEY_ERR_BAD_DESC); }
+    if (G < 0 || G > 256 || (G > 1 && K > 2)) { h->err = "wgs_per_inst must be in [0, 256] (and inst_per_wg <= 2 with it)"; return fail(SPICEY_ERR_BAD_DESC); }
     if (G == 0) {
       G = 1;
+      // (with dense fronts the group barriers that are left belong to a dozen wide levels, and the front tree wants one
+      // workgroup per subtree: 64 CUs per instance; without them every one of ~600 barriers per step grows with G)
+      const int gmax = P.nFronts > 0 ? 64 : 16;
       if (K <= 2 && P.nLU >= 40000)
-        while (G * 2 <= 16 && h->grid * G * 2 <= ncu) G *= 2;
+        while (G * 2 <= gmax && h->grid * G * 2 <= ncu) G *= 2;
     }
     if (h->grid * G > ncu) G = std::max(1, ncu / h->grid);
     h->G = G;

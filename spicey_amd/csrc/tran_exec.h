@@ -57,9 +57,11 @@
 #define SPICEY_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #endif
 #define SPICEY_NOUNROLL _Pragma("unroll 1")  // thread-strided loops run 1-2 trips: unrolling only costs VGPRs
+#define SPICEY_UNROLL _Pragma("unroll")      // small fixed-trip loops over a register array: without it the array is indexed through s_set_gpr_idx
 #define SPICEY_SCHED_FENCE __builtin_amdgcn_sched_barrier(0)  // keep the K instances' code from being interleaved
 #else
 #define SPICEY_NOUNROLL
+#define SPICEY_UNROLL
 #define SPICEY_SCHED_FENCE
 #define SPICEY_UNIFORM(x) (x)
 #define SPICEY_OPAQUE(x) (void)(x)
@@ -1225,15 +1227,22 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
         // Group mode: the backward levels carry little work (mesh 100^2: 172 k products over 297 levels) but each
         // would cost a cross-workgroup barrier (~4.7 us): ONE workgroup of the group walks them with its own
         // workgroup barriers, the others wait at the single group barrier behind the chain.
+        // (with dense fronts the levels that are left are the WIDE ones at the bottom of the tree — thousands of rows each,
+        // the interface phase included: those go to all workgroups, one group barrier each)
+        bool local_run = false;
         for (int l = P.nLevels - 1; l >= 0; l--) {
-          if (P.bk_lvl_slice[l] == P.bk_lvl_slice[l + 1]) continue;
-          if (use_fronts && l == P.front_cut) {  // the interface phase is wide (every row below the cut): all workgroups
+          const uint32_t nsl = P.bk_lvl_slice[l + 1] - P.bk_lvl_slice[l];
+          if (nsl == 0) continue;
+          if (use_fronts && nsl > 16) {
+            if (local_run) ex.sync();
+            local_run = false;
             ex.phase(SPICEY_PH_K0 + 31, [&](int tid) { ph.k_level(tid, l); });
             continue;
           }
           ex.local_phase([&](int tid) { phl.k_level(tid, l); });
+          local_run = true;
         }
-        ex.sync();
+        if (local_run || !use_fronts) ex.sync();
       } else {
         for (int l = P.nLevels - 1; l >= 0; l--) {
           if (P.bk_lvl_slice[l] == P.bk_lvl_slice[l + 1]) continue;
