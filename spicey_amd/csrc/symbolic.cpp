@@ -683,10 +683,22 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   hp.fronts.clear(); hp.fr_asm.clear(); hp.fr_bnd.clear(); hp.fr_child.clear(); hp.fr_rel.clear(); hp.front_work.clear();
   if (Lc > 0) {
     auto pad16 = [](int x) { return (x + 15) & ~15; };
+    const bool relax_fronts = !getenv("SPICEY_FRONT_EXACT");  // experiments: exact supernodes only
     for (int k = 0; k < n; k++) {
       if (hp.level[k] < Lc) continue;
-      const bool merge = k > 0 && front_of[k - 1] >= 0 && !upper[k - 1].empty() && upper[k - 1][0] == k &&
-                         upper[k - 1].size() == upper[k].size() + 1;
+      // exact nesting (upper[k-1] = {k} + upper[k]) always merges; a RELAXED merge also takes a chain pivot whose row is
+      // a little shorter than its parent's (the missing positions become explicit zeros of the dense front): every front
+      // costs a fixed ~10 us of assembly / hand-over latency whatever its size, and the small chain fronts are the many.
+      // Relaxed merges stop where the front would outgrow LDS residency (128 padded rows).
+      bool merge = k > 0 && front_of[k - 1] >= 0 && !upper[k - 1].empty() && upper[k - 1][0] == k;
+      if (merge) {
+        const size_t grow = upper[k].size() + 1 - upper[k - 1].size();  // (upper[k-1] \ {k} is a subset of upper[k])
+        const int pp = hp.fronts[front_of[k - 1]].p;
+        const bool exact = grow == 0;
+        const bool relaxed = relax_fronts && grow <= std::max<size_t>(4, upper[k].size() / 4) &&
+                             pad16(pp + 1) + pad16((int)upper[k].size()) <= 128;
+        merge = exact || relaxed;
+      }
       if (merge) {
         front_of[k] = front_of[k - 1];
         hp.fronts[front_of[k]].p++;
@@ -734,7 +746,10 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
         work += (double)upper[k].size() * (double)(upper[k].size() + 1);
       }
       f.asm_n = (uint32_t)(hp.fr_asm.size() / 2) - f.asm0;
-      hp.front_work.push_back(work + 64.0 * f.Mp);  // + a per-front overhead so that tiny fronts still count
+      // schedule weight in shader cycles: trailing updates at the MFMA rate (64 multiply-adds per cycle per CU), plus the
+      // measured fixed costs — ~5 us per front (assembly, hand-over, store: latency of a few dependent L2 round trips),
+      // ~3.5 us per panel (diagonal block, triangular solves), and the staged path of a front too large for LDS
+      hp.front_work.push_back(work / 64.0 + 12000.0 + 8000.0 * (f.Pp / 16) + (f.Mp > 128 ? 60000.0 : 0.0));
     }
     if (off >= ((uint64_t)1 << 31) || max_mp > 448) ok = false;  // 32-bit offsets; panels of the largest front must fit LDS
     for (size_t fi = 0; fi < hp.fronts.size() && ok; fi++) {
