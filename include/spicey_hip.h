@@ -186,6 +186,27 @@ int32_t spicey_debug_phase_cycles(SpiceyHandle *h, uint64_t *out, int32_t n);
  * [10] fronts backward, [11] publish + group barrier, [12..20] inside the fronts, [40] backward levels, [4] Z. */
 int32_t spicey_debug_phase_cycles_wg(SpiceyHandle *h, int32_t wg, uint64_t *out, int32_t n);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Several devices behind one handle (SURVEY.md §8(b) "device ordinal(s)", §8(e)): the n_inst instances of the descriptor
+ * are block-partitioned over the listed devices (instance i -> devices[floor(i * n_dev / n_inst)], the partition of
+ * spicey_amd/dist.py), one SpiceyHandle + stream per device inside THIS process; spicey_run_multi launches every shard
+ * from its own host thread and each shard's results land directly in its slice of the caller's single host buffers
+ * (that is the gather).  No data-path exchange between devices: instances are independent (simulateTRAN.ts:130 is one
+ * circuit, one thread).  A device may be listed more than once (it then gets several shards).  opt->device is ignored.
+ *   devices   [n_dev] HIP device ordinals, n_dev >= 1; n_dev > n_inst leaves the surplus devices idle
+ * Errors: the first failing shard's status; spicey_multi_last_error names the device. */
+typedef struct SpiceyMulti SpiceyMulti;
+int32_t spicey_create_multi(const SpiceyDesc *desc, const SpiceyOptions *opt, const int32_t *devices, int32_t n_dev, SpiceyMulti **out);
+/* Same buffers as spicey_run, for ALL instances: out_v [n_inst][steps+1][n_out], out_i, iters likewise or NULL. Blocking. */
+int32_t spicey_run_multi(SpiceyMulti *m, int64_t steps, double dt, const double *src_table, double *out_v, double *out_i, int32_t *iters);
+int32_t spicey_get_state_multi(SpiceyMulti *m, double *C_vprev, double *L_iprev, double *D_vdprev, int32_t *S_ison);
+/* Shard `shard` (0 .. n_shards-1): its SpiceyInfo, first instance and instance count; returns SPICEY_ERR_BAD_DESC past the end. */
+int32_t spicey_multi_get_shard(SpiceyMulti *m, int32_t shard, SpiceyInfo *info, int32_t *device, int32_t *first_inst, int32_t *n_inst);
+int64_t spicey_multi_last_solve_count(SpiceyMulti *m);  /* all shards */
+double spicey_multi_last_kernel_ms(SpiceyMulti *m);     /* the slowest shard's kernel */
+const char *spicey_multi_last_error(SpiceyMulti *m);    /* NULL handle -> the calling thread's last failed create */
+void spicey_destroy_multi(SpiceyMulti *m);
+
 /* Library build info: "spicey_hip <abi> gfx950 …" */
 const char *spicey_version(void);
 

@@ -538,3 +538,124 @@ extern "C" int32_t spicey_debug_phase_cycles_wg(SpiceyHandle *h, int32_t wg, uin
   for (int i = 0; i < n && i < 72; i++) out[i] = tmp[i];
   return 72;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Several devices behind one handle: instance shards, one SpiceyHandle per shard, host threads around the blocking runs.
+#include <thread>
+
+struct SpiceyMulti {
+  struct Shard { SpiceyHandle *h = nullptr; int device = 0, first = 0, count = 0; };
+  std::vector<Shard> shards;
+  int n_inst = 0;
+  int nC = 0, nL = 0, nD = 0, nS = 0, nOut = 0, nCur = 0;
+  int64_t last_solves = 0;
+  double last_ms = 0.0;
+  std::string err;
+};
+
+extern "C" const char *spicey_multi_last_error(SpiceyMulti *m) { return m ? m->err.c_str() : g_err.c_str(); }
+
+extern "C" void spicey_destroy_multi(SpiceyMulti *m) {
+  if (!m) return;
+  for (auto &s : m->shards) spicey_destroy(s.h);
+  delete m;
+}
+
+extern "C" int32_t spicey_create_multi(const SpiceyDesc *desc, const SpiceyOptions *opt, const int32_t *devices, int32_t n_dev, SpiceyMulti **out) {
+  if (!out) { g_err = "null out pointer"; return SPICEY_ERR_BAD_DESC; }
+  *out = nullptr;
+  if (!desc || !devices || n_dev < 1) { g_err = "spicey_create_multi needs a descriptor and a list of >= 1 devices"; return SPICEY_ERR_BAD_DESC; }
+  if (desc->n_inst < 1) { g_err = "negative count or n_inst < 1"; return SPICEY_ERR_BAD_DESC; }
+  for (int d = 0; d < n_dev; d++)
+    if (devices[d] < 0) { g_err = "device ordinal out of range"; return SPICEY_ERR_BAD_DESC; }
+  SpiceyMulti *m = new SpiceyMulti();
+  m->n_inst = desc->n_inst;
+  const int ni = desc->n_inst;
+  for (int d = 0; d < n_dev; d++) {
+    // block partition: shard d = instances [ceil(d ni / n_dev), ceil((d + 1) ni / n_dev))
+    const int lo = (int)(((int64_t)d * ni + n_dev - 1) / n_dev), hi = (int)(((int64_t)(d + 1) * ni + n_dev - 1) / n_dev);
+    if (hi <= lo) continue;
+    SpiceyDesc sd = *desc;
+    sd.n_inst = hi - lo;
+    auto adv = [&](const double *p, int n) { return p ? p + (size_t)lo * (size_t)n : p; };
+    sd.R_val = adv(desc->R_val, desc->nR);
+    sd.C_val = adv(desc->C_val, desc->nC); sd.C_vprev = adv(desc->C_vprev, desc->nC);
+    sd.L_val = adv(desc->L_val, desc->nL); sd.L_iprev = adv(desc->L_iprev, desc->nL);
+    sd.S_ron = adv(desc->S_ron, desc->nS); sd.S_roff = adv(desc->S_roff, desc->nS);
+    sd.S_von = adv(desc->S_von, desc->nS); sd.S_voff = adv(desc->S_voff, desc->nS);
+    sd.S_ison = desc->S_ison ? desc->S_ison + (size_t)lo * (size_t)desc->nS : nullptr;
+    sd.D_is = adv(desc->D_is, desc->nD); sd.D_n = adv(desc->D_n, desc->nD); sd.D_vdprev = adv(desc->D_vdprev, desc->nD);
+    SpiceyOptions so{};
+    if (opt) so = *opt;
+    so.device = devices[d];
+    SpiceyMulti::Shard s;
+    s.device = devices[d]; s.first = lo; s.count = hi - lo;
+    const int32_t rc = spicey_create(&sd, &so, &s.h);
+    if (rc != SPICEY_OK) {
+      char buf[64];
+      snprintf(buf, sizeof(buf), " (shard %d on device %d)", d, devices[d]);
+      g_err += buf;
+      spicey_destroy_multi(m);
+      return rc;
+    }
+    m->shards.push_back(s);
+  }
+  const SpiceyProg &P = m->shards[0].h->hp.hdr;
+  m->nC = P.nC; m->nL = P.nL; m->nD = P.nD; m->nS = P.nS; m->nOut = P.nOut; m->nCur = P.nCur;
+  *out = m;
+  return SPICEY_OK;
+}
+
+extern "C" int32_t spicey_run_multi(SpiceyMulti *m, int64_t steps, double dt, const double *src_table, double *out_v, double *out_i, int32_t *iters) {
+  if (!m) return SPICEY_ERR_BAD_DESC;
+  if (steps < 0 || !out_v) { m->err = "bad run arguments"; return SPICEY_ERR_BAD_DESC; }
+  const size_t np = (size_t)steps + 1;
+  std::vector<int32_t> rcs(m->shards.size(), SPICEY_OK);
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < m->shards.size(); i++) {
+    th.emplace_back([&, i]() {
+      const SpiceyMulti::Shard &s = m->shards[i];
+      rcs[i] = spicey_run(s.h, steps, dt, src_table, out_v + (size_t)s.first * np * (size_t)m->nOut,
+                          out_i ? out_i + (size_t)s.first * np * (size_t)m->nCur : nullptr, iters ? iters + (size_t)s.first * np : nullptr);
+    });
+  }
+  for (auto &t : th) t.join();
+  m->last_solves = 0;
+  m->last_ms = 0.0;
+  int32_t rc = SPICEY_OK;
+  for (size_t i = 0; i < m->shards.size(); i++) {
+    const SpiceyMulti::Shard &s = m->shards[i];
+    if (rcs[i] != SPICEY_OK && rc == SPICEY_OK) {  // first failing shard in instance order; its instance number made global
+      rc = rcs[i];
+      char buf[96];
+      snprintf(buf, sizeof(buf), " (shard %d: instances %d..%d on device %d)", (int)i, s.first, s.first + s.count - 1, s.device);
+      m->err = std::string(spicey_last_error(s.h)) + buf;
+    }
+    m->last_solves += spicey_last_solve_count(s.h);
+    m->last_ms = std::max(m->last_ms, spicey_last_kernel_ms(s.h));
+  }
+  return rc;
+}
+
+extern "C" int32_t spicey_get_state_multi(SpiceyMulti *m, double *C_vprev, double *L_iprev, double *D_vdprev, int32_t *S_ison) {
+  if (!m) return SPICEY_ERR_BAD_DESC;
+  for (auto &s : m->shards) {
+    const int32_t rc = spicey_get_state(s.h, C_vprev ? C_vprev + (size_t)s.first * m->nC : nullptr, L_iprev ? L_iprev + (size_t)s.first * m->nL : nullptr,
+                                        D_vdprev ? D_vdprev + (size_t)s.first * m->nD : nullptr, S_ison ? S_ison + (size_t)s.first * m->nS : nullptr);
+    if (rc != SPICEY_OK) { m->err = spicey_last_error(s.h); return rc; }
+  }
+  return SPICEY_OK;
+}
+
+extern "C" int32_t spicey_multi_get_shard(SpiceyMulti *m, int32_t shard, SpiceyInfo *info, int32_t *device, int32_t *first_inst, int32_t *n_inst) {
+  if (!m || shard < 0 || shard >= (int32_t)m->shards.size()) return SPICEY_ERR_BAD_DESC;
+  const SpiceyMulti::Shard &s = m->shards[shard];
+  if (info) spicey_get_info(s.h, info);
+  if (device) *device = s.device;
+  if (first_inst) *first_inst = s.first;
+  if (n_inst) *n_inst = s.count;
+  return SPICEY_OK;
+}
+
+extern "C" int64_t spicey_multi_last_solve_count(SpiceyMulti *m) { return m ? m->last_solves : 0; }
+extern "C" double spicey_multi_last_kernel_ms(SpiceyMulti *m) { return m ? m->last_ms : 0.0; }

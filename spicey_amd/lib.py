@@ -22,6 +22,8 @@ EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "s
            "spicey_last_solve_count",
            "spicey_last_kernel_ms", "spicey_get_info", "spicey_last_error", "spicey_destroy", "spicey_version",
            "spicey_debug_phase_cycles", "spicey_debug_phase_cycles_wg",
+           "spicey_create_multi", "spicey_run_multi", "spicey_get_state_multi", "spicey_multi_get_shard", "spicey_multi_last_solve_count",
+           "spicey_multi_last_kernel_ms", "spicey_multi_last_error", "spicey_destroy_multi",
            "spicey_ac_create", "spicey_ac_run", "spicey_ac_get_info", "spicey_ac_last_kernel_ms", "spicey_ac_last_error", "spicey_ac_destroy",
            "spicey_format_tran", "spicey_to_precision6"]
 
@@ -68,6 +70,22 @@ def load():
     L.spicey_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32]
     L.spicey_debug_phase_cycles_wg.restype = C.c_int32
     L.spicey_debug_phase_cycles_wg.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.c_int32]
+    L.spicey_create_multi.restype = C.c_int32
+    L.spicey_create_multi.argtypes = [C.POINTER(abi.SpiceyDesc), C.POINTER(abi.SpiceyOptions), i32p, C.c_int32, C.POINTER(vp)]
+    L.spicey_run_multi.restype = C.c_int32
+    L.spicey_run_multi.argtypes = [vp, C.c_int64, C.c_double, f64p, f64p, f64p, i32p]
+    L.spicey_get_state_multi.restype = C.c_int32
+    L.spicey_get_state_multi.argtypes = [vp, f64p, f64p, f64p, i32p]
+    L.spicey_multi_get_shard.restype = C.c_int32
+    L.spicey_multi_get_shard.argtypes = [vp, C.c_int32, C.POINTER(abi.SpiceyInfo), i32p, i32p, i32p]
+    L.spicey_multi_last_solve_count.restype = C.c_int64
+    L.spicey_multi_last_solve_count.argtypes = [vp]
+    L.spicey_multi_last_kernel_ms.restype = C.c_double
+    L.spicey_multi_last_kernel_ms.argtypes = [vp]
+    L.spicey_multi_last_error.restype = C.c_char_p
+    L.spicey_multi_last_error.argtypes = [vp]
+    L.spicey_destroy_multi.restype = None
+    L.spicey_destroy_multi.argtypes = [vp]
     L.spicey_ac_create.restype = C.c_int32
     L.spicey_ac_create.argtypes = [C.POINTER(abi.SpiceyDesc), C.POINTER(abi.SpiceyOptions), C.POINTER(vp)]
     L.spicey_ac_run.restype = C.c_int32
@@ -199,6 +217,68 @@ class Handle:
     def close(self) -> None:
         if getattr(self, "h", None):
             self.L.spicey_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiHandle:
+    """spicey_create_multi / spicey_run_multi: the instances of one FlatCircuit block-partitioned over several devices
+    inside this process, results gathered into one host buffer (SURVEY.md §8(b) "device ordinal(s)", §8(e))."""
+
+    def __init__(self, flat: abi.FlatCircuit, devices, **opts):
+        self.L = load()
+        self.flat = flat
+        opt = abi.SpiceyOptions()
+        opt.want_currents = 1
+        for k, v in opts.items():
+            setattr(opt, k, int(v))
+        d = flat.desc()
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        hp = C.c_void_p()
+        rc = self.L.spicey_create_multi(C.byref(d), C.byref(opt), _p(devs, C.c_int32) if len(devs) else None, len(devs), C.byref(hp))
+        if rc != abi.OK:
+            msg = self.L.spicey_multi_last_error(None)
+            raise SpiceyNativeError(f"spicey_create_multi failed ({rc}): {msg.decode() if msg else ''}")
+        self.h = hp
+
+    def shards(self) -> list:
+        out = []
+        i = 0
+        while True:
+            info = abi.SpiceyInfo()
+            dev, first, cnt = C.c_int32(), C.c_int32(), C.c_int32()
+            if self.L.spicey_multi_get_shard(self.h, i, C.byref(info), C.byref(dev), C.byref(first), C.byref(cnt)) != abi.OK:
+                return out
+            out.append({"device": dev.value, "first_inst": first.value, "n_inst": cnt.value, "info": info.as_dict()})
+            i += 1
+
+    def run(self, steps: int, dt: float, src: np.ndarray, want_currents: bool = True, want_iters: bool = True) -> dict:
+        f = self.flat
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        out_v = np.empty((f.n_inst, steps + 1, f.n_out))
+        out_i = np.empty((f.n_inst, steps + 1, f.n_cur)) if want_currents else None
+        iters = np.zeros((f.n_inst, steps + 1), np.int32) if want_iters else None
+        rc = self.L.spicey_run_multi(self.h, steps, dt, _p(src, C.c_double), _p(out_v, C.c_double), _p(out_i, C.c_double), _p(iters, C.c_int32))
+        detail = self.L.spicey_multi_last_error(self.h).decode() if rc != abi.OK else ""
+        res = {"status": rc, "detail": detail, "out_v": out_v, "out_i": out_i, "iters": iters}
+        if rc == abi.OK:
+            st = {"C_vprev": np.zeros((f.n_inst, f.nC)), "L_iprev": np.zeros((f.n_inst, f.nL)), "D_vdprev": np.zeros((f.n_inst, f.nD)),
+                  "S_ison": np.zeros((f.n_inst, f.nS), np.int32)}
+            self.L.spicey_get_state_multi(self.h, _p(st["C_vprev"], C.c_double), _p(st["L_iprev"], C.c_double), _p(st["D_vdprev"], C.c_double),
+                                          _p(st["S_ison"], C.c_int32))
+            res["state"] = st
+            res["solves"] = self.L.spicey_multi_last_solve_count(self.h)
+            res["kernel_ms"] = self.L.spicey_multi_last_kernel_ms(self.h)
+        return res
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.L.spicey_destroy_multi(self.h)
             self.h = None
 
     def __del__(self):

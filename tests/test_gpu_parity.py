@@ -598,3 +598,43 @@ def test_dense_fronts_upper_tree(oracle_backend):
     dt3, st3 = abi.computeEffectiveTimeStep(tr["dt"], tr["tstop"])
     bad = HipBackend(front_cut=1, interpreter=1).run(abi.flatten(c3), st3, dt3, abi.source_table(c3, dt3, st3))
     assert bad["status"] == abi.ERR_SINGULAR
+
+
+def test_multi_device_handle_matches_single_handle(oracle_backend):
+    """spicey_create_multi / spicey_run_multi: instances block-partitioned over the listed devices inside one process, one
+    handle + host thread per shard, results landing in the caller's single buffer.  On the one-GPU box the device is
+    listed several times: the shards must reproduce the single-handle run bit for bit (same program, same arithmetic),
+    states and iteration counts included, for even and ragged partitions, with more devices than instances, and an
+    out-of-range ordinal must be refused."""
+    from spicey_amd.lib import Handle, MultiHandle, SpiceyNativeError
+    flat, dt, steps, src = synth.chain_batch("diode_chain", 300, range(1, 12), tran=".tran 1e-6 4e-5")  # 11 instances
+    single = Handle(flat).run(steps, dt, src)
+    ref = oracle_backend.run(flat, steps, dt, src)
+    assert single["status"] == 0 and tol_ratio(single["out_v"], ref["out_v"]).max() <= 1.0
+    for devs in ([0], [0, 0], [0, 0, 0, 0], [0] * 16):
+        m = MultiHandle(flat, devs)
+        sh = m.shards()
+        assert sum(s["n_inst"] for s in sh) == 11 and [s["first_inst"] for s in sh] == sorted(s["first_inst"] for s in sh)
+        assert len(sh) == min(len(devs), 11) and max(s["n_inst"] for s in sh) - min(s["n_inst"] for s in sh) <= 1
+        got = m.run(steps, dt, src)
+        assert got["status"] == 0, got["detail"]
+        assert np.array_equal(got["out_v"], single["out_v"]) and np.array_equal(got["out_i"], single["out_i"]), devs
+        assert np.array_equal(got["iters"], single["iters"]) and got["solves"] == single["solves"]
+        for k in ("C_vprev", "D_vdprev"):
+            assert np.array_equal(got["state"][k], single["state"][k]), (devs, k)
+        again = m.run(steps, dt, src)  # second run continues from the shards' end states, like one handle does
+        m.close()
+    cont = Handle(flat)
+    cont.run(steps, dt, src)
+    assert np.array_equal(again["out_v"], cont.run(steps, dt, src)["out_v"])
+    with pytest.raises(SpiceyNativeError, match="device ordinal out of range"):
+        MultiHandle(flat, [0, 99])
+    # a singular instance in the second shard (near_sing_c with its 1e14-ohm leak raised to 1e16: pivot 0, solveReal.ts:28):
+    # reported with its shard, not hidden by the healthy first shard
+    c4 = parseNetlist(golden_netlist(load_golden("near_sing_c")))
+    f4 = abi.flatten(c4).replicate(4)
+    f4.R_val[3, [r.name for r in c4.R].index("R3")] = 1e16
+    tr = c4.analyses["tran"]
+    dt4, st4 = abi.computeEffectiveTimeStep(tr["dt"], tr["tstop"])
+    r = MultiHandle(f4, [0, 0]).run(st4, dt4, abi.source_table(c4, dt4, st4))
+    assert r["status"] == abi.ERR_SINGULAR and "shard 1" in r["detail"] and "singular at inst 1 step 0" in r["detail"]

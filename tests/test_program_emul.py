@@ -243,6 +243,21 @@ def test_no_gpu_fails_loudly():
         simulate(synth.rc_ladder(8))
 
 
+def test_multi_device_descriptor_validation():
+    """spicey_create_multi (several devices behind one handle): argument checks run before any device is touched; without
+    a GPU a valid request stops at NO_DEVICE like spicey_create (no CPU path)."""
+    import torch
+    from spicey_amd.lib import MultiHandle, SpiceyNativeError
+    flat, dt, steps, src = synth.chain_batch("rc_ladder", 10, [1, 2, 3], tran=".tran 1e-6 5e-6")
+    with pytest.raises(SpiceyNativeError, match=r"\(2\).*list of >= 1 devices"):
+        MultiHandle(flat, [])
+    with pytest.raises(SpiceyNativeError, match=r"\(2\).*device ordinal out of range"):
+        MultiHandle(flat, [0, -1])
+    if not torch.cuda.is_available():
+        with pytest.raises(SpiceyNativeError, match=r"\(4\).*no HIP device.*shard 0 on device 0"):
+            MultiHandle(flat, [0, 0])
+
+
 def test_product_does_not_touch_oracle():
     """No file of the shipped package imports, loads or links anything under oracle/ or tests/."""
     pkg = os.path.join(REPO, "spicey_amd")

@@ -28,6 +28,15 @@ const { symbols: C } = dlopen(libPath, {
     returns: FFIType.i32,
   },
   spicey_get_state: { args: [FFIType.ptr, FFIType.ptr, FFIType.ptr, FFIType.ptr, FFIType.ptr], returns: FFIType.i32 },
+  // several devices behind one handle: instances block-partitioned over `devices`, results gathered into one buffer
+  spicey_create_multi: { args: [FFIType.ptr, FFIType.ptr, FFIType.ptr, FFIType.i32, FFIType.ptr], returns: FFIType.i32 },
+  spicey_run_multi: {
+    args: [FFIType.ptr, FFIType.i64, FFIType.f64, FFIType.ptr, FFIType.ptr, FFIType.ptr, FFIType.ptr],
+    returns: FFIType.i32,
+  },
+  spicey_get_state_multi: { args: [FFIType.ptr, FFIType.ptr, FFIType.ptr, FFIType.ptr, FFIType.ptr], returns: FFIType.i32 },
+  spicey_multi_last_error: { args: [FFIType.ptr], returns: FFIType.ptr },
+  spicey_destroy_multi: { args: [FFIType.ptr], returns: FFIType.void },
   spicey_last_error: { args: [FFIType.ptr], returns: FFIType.ptr },
   spicey_last_solve_count: { args: [FFIType.ptr], returns: FFIType.i64 },
   spicey_destroy: { args: [FFIType.ptr], returns: FFIType.void },
