@@ -38,7 +38,9 @@ def simulateTRAN(ckt: ParsedCircuit, backend=None, as_lists: bool = True) -> Opt
     if not tran:
         return None
     dt, steps = abi.computeEffectiveTimeStep(tran["dt"], tran["tstop"])
-    flat = abi.flatten(ckt)
+    # .PRINT TRAN probes go DOWN to the device (SpiceyDesc.out_nodes): the reference computes every node and filters
+    # afterwards (simulateTRAN.ts:240-249); here only the probed columns are written, moved and re-keyed
+    flat = abi.flatten(ckt, probe_filter=True)
     src = abi.source_table(ckt, dt, steps)
     be = backend if backend is not None else _default_backend()
     res = be.run(flat, steps, dt, src, want_currents=True)
@@ -57,8 +59,9 @@ def simulateTRAN(ckt: ParsedCircuit, backend=None, as_lists: bool = True) -> Opt
     names = ckt.nodes.rev
     node_voltages: Dict[str, object] = {}
     # JS: later duplicate names cannot occur (interned), order = js key order of insertion order
-    order = js_object_key_order([names[i] for i in range(1, ckt.nodes.count())])
-    col = {names[i]: i - 1 for i in range(1, ckt.nodes.count())}
+    recorded = [int(i) for i in flat.out_nodes] if flat.out_nodes is not None and len(flat.out_nodes) else list(range(1, ckt.nodes.count()))
+    order = js_object_key_order([names[i] for i in recorded])
+    col = {names[i]: c for c, i in enumerate(recorded)}
     for name in order:
         node_voltages[name] = conv(out_v[:, col[name]])
 
@@ -89,9 +92,7 @@ def simulateTRAN(ckt: ParsedCircuit, backend=None, as_lists: bool = True) -> Opt
     for i, s in enumerate([s for s in ckt.S if s.model is not None]):
         s.isOn = bool(st["S_ison"][0, i])
 
-    if len(ckt.probes["tran"]) > 0:  # :240-249
-        upper = [p.upper() for p in ckt.probes["tran"]]
-        node_voltages = {k: v for k, v in node_voltages.items() if k.upper() in upper}
+    # (probes, if any, were applied on the device: node_voltages holds exactly the probed nodes, in JS key order)
     return {"times": times, "nodeVoltages": node_voltages, "elementCurrents": element_currents,
             "iterations": res.get("iters")}
 

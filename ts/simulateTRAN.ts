@@ -55,27 +55,51 @@ function simulateTRAN(ckt: ParsedCircuit) {
   }
 
   const flat = flatten(ckt)
+  // `.PRINT TRAN v(..)` probes are resolved to node ids here and applied by the device, which then writes, and this
+  // function re-keys, only those columns (the reference records every node and filters at the end, :240-249)
+  const wanted = ckt.probes.tran.map((p) => p.toUpperCase())
+  const recorded: number[] = []
+  for (let id = 1; id <= flat.nNodes; id++) {
+    if (wanted.length === 0 || wanted.includes(ckt.nodes.rev[id]!.toUpperCase())) recorded.push(id)
+  }
+  if (wanted.length > 0) flat.outNodes = Int32Array.from(recorded)
   const res = runTransientNative(flat, steps, dt, src)
 
-  // re-key: plain number[] per canonical node name / element name, JS object key order (:139-144, :164-219)
-  const nNodes = flat.nNodes
-  const nodeVoltages: Record<string, number[]> = {}
-  ckt.nodes.rev.forEach((name, id) => {
-    if (id !== 0) nodeVoltages[name] = []
-  })
-  for (let id = 1; id <= nNodes; id++) {
-    const series = nodeVoltages[ckt.nodes.rev[id]!]
-    if (!series) continue
-    for (let step = 0; step <= steps; step++) series.push(res.outV[step * nNodes + (id - 1)]!)
+  // re-key: one strided column copy per recorded node / per element, then a plain number[] (the reference's result type);
+  // keys enter the objects in the reference's insertion order so that JS key order (integer-like names first) matches
+  const np1 = steps + 1
+  const column = (buf: Float64Array, stride: number, col: number): number[] => {
+    const out = new Float64Array(np1)
+    for (let s = 0, k = col; s < np1; s++, k += stride) out[s] = buf[k]!
+    return Array.from(out)
   }
-  const elementCurrents: Record<string, number[]> = {}
+  const nOut = recorded.length
+  const nodeVoltages: Record<string, number[]> = {}
+  recorded.forEach((id, c) => {
+    nodeVoltages[ckt.nodes.rev[id]!] = column(res.outV, nOut, c)
+  })
   const names = [
     ...ckt.R.map((e) => e.name), ...ckt.C.map((e) => e.name), ...ckt.L.map((e) => e.name), ...ckt.V.map((e) => e.name),
     ...ckt.S.filter((s) => s.model).map((e) => e.name), ...ckt.D.filter((d) => d.model).map((e) => e.name),
   ]
   const nCur = names.length
-  for (let step = 0; step <= steps; step++)
-    for (let j = 0; j < nCur; j++) (elementCurrents[names[j]!] ||= []).push(res.outI[step * nCur + j]!)
+  const elementCurrents: Record<string, number[]> = {}
+  const columnsOf: Map<string, number[]> = new Map()
+  names.forEach((nm, j) => {
+    const cols = columnsOf.get(nm)
+    if (cols) cols.push(j)
+    else columnsOf.set(nm, [j])
+  })
+  for (const [nm, cols] of columnsOf) {
+    if (cols.length === 1) {
+      elementCurrents[nm] = column(res.outI, nCur, cols[0]!)
+    } else {
+      // elements that share a name share one array in the reference, interleaved per step
+      const out: number[] = []
+      for (let s = 0; s < np1; s++) for (const j of cols) out.push(res.outI[s * nCur + j]!)
+      elementCurrents[nm] = out
+    }
+  }
 
   // state write-back (:221-237, :122-124): a second simulateTRAN(ckt) continues from here
   ckt.C.forEach((c, i) => (c.vPrev = res.state.vPrev[i]!))
@@ -83,14 +107,6 @@ function simulateTRAN(ckt: ParsedCircuit) {
   ckt.D.filter((d) => d.model).forEach((d, i) => (d.vdPrev = res.state.vdPrev[i]!))
   ckt.S.filter((s) => s.model).forEach((s, i) => (s.isOn = res.state.isOn[i] !== 0))
 
-  if (ckt.probes.tran.length > 0) {
-    const probedVoltages: Record<string, number[]> = {}
-    const upperProbes = ckt.probes.tran.map((p) => p.toUpperCase())
-    for (const nodeName in nodeVoltages) {
-      if (upperProbes.includes(nodeName.toUpperCase())) probedVoltages[nodeName] = nodeVoltages[nodeName]!
-    }
-    return { times, nodeVoltages: probedVoltages, elementCurrents }
-  }
   return { times, nodeVoltages, elementCurrents }
 }
 

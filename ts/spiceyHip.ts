@@ -59,6 +59,8 @@ export type FlatCircuit = {
     ron: Float64Array; roff: Float64Array; von: Float64Array; voff: Float64Array; isOn: Int32Array
   }
   D: { np: Int32Array; nm: Int32Array; is: Float64Array; n: Float64Array; vdPrev: Float64Array }
+  /** node ids (1-based) to record, in this order; absent / empty = every node in id order (SpiceyDesc.out_nodes) */
+  outNodes?: Int32Array
 }
 
 // bun:ffi cannot take a pointer to an empty TypedArray; zero-length arrays are passed as NULL
@@ -82,10 +84,13 @@ function packDesc(f: FlatCircuit): { buf: ArrayBuffer; keep: ArrayBufferView[] }
   p64("S_n1", f.S.n1); p64("S_n2", f.S.n2); p64("S_cp", f.S.cp); p64("S_cn", f.S.cn)
   p64("S_ron", f.S.ron); p64("S_roff", f.S.roff); p64("S_von", f.S.von); p64("S_voff", f.S.voff); p64("S_ison", f.S.isOn)
   p64("D_np", f.D.np); p64("D_nm", f.D.nm); p64("D_is", f.D.is); p64("D_n", f.D.n); p64("D_vdprev", f.D.vdPrev)
-  i32("n_out", 0) // all nodes; probe filtering stays in TS like the reference (simulateTRAN.ts:240-249)
-  dv.setBigUint64(L.out_nodes.offset, 0n, true)
+  // .PRINT probes are applied on the device: only the probed columns are written and copied back (the reference
+  // computes every node and filters afterwards, simulateTRAN.ts:240-249)
+  const outNodes = f.outNodes && f.outNodes.length ? f.outNodes : new Int32Array(0)
+  i32("n_out", outNodes.length)
+  p64("out_nodes", outNodes)
   const keep = [f.R.n1, f.R.n2, f.R.val, f.C.n1, f.C.n2, f.C.val, f.C.vPrev, f.L.n1, f.L.n2, f.L.val, f.L.iPrev, f.V.n1, f.V.n2,
-    f.S.n1, f.S.n2, f.S.cp, f.S.cn, f.S.ron, f.S.roff, f.S.von, f.S.voff, f.S.isOn, f.D.np, f.D.nm, f.D.is, f.D.n, f.D.vdPrev]
+    f.S.n1, f.S.n2, f.S.cp, f.S.cn, f.S.ron, f.S.roff, f.S.von, f.S.voff, f.S.isOn, f.D.np, f.D.nm, f.D.is, f.D.n, f.D.vdPrev, outNodes]
   return { buf, keep }
 }
 
@@ -95,7 +100,7 @@ function lastError(h: Pointer | null): string {
 }
 
 export type NativeTranResult = {
-  outV: Float64Array // [steps+1][nNodes]
+  outV: Float64Array // [steps+1][nOut], nOut = outNodes.length or nNodes
   outI: Float64Array // [steps+1][nCur], order R, C, L, V, S, D
   iters: Int32Array // [steps+1]
   state: { vPrev: Float64Array; iPrev: Float64Array; vdPrev: Float64Array; isOn: Int32Array }
@@ -113,7 +118,8 @@ export function runTransientNative(f: FlatCircuit, steps: number, dt: number, sr
   const h = Number(hOut[0]) as unknown as Pointer
   try {
     const nCur = f.R.n1.length + f.C.n1.length + f.L.n1.length + f.V.n1.length + f.S.n1.length + f.D.np.length
-    const outV = new Float64Array((steps + 1) * Math.max(f.nNodes, 1))
+    const nOut = f.outNodes && f.outNodes.length ? f.outNodes.length : f.nNodes
+    const outV = new Float64Array((steps + 1) * Math.max(nOut, 1))
     const outI = new Float64Array((steps + 1) * Math.max(nCur, 1))
     const iters = new Int32Array(steps + 1)
     rc = C.spicey_run(h, BigInt(steps), dt, srcTable.length ? ptr(srcTable) : null, ptr(outV), ptr(outI), ptr(iters))
