@@ -131,7 +131,11 @@ extern "C" int32_t spicey_ac_create(const SpiceyDesc *desc, const SpiceyOptions 
   }
   h->dprog = h->hp.bind(h->d_blob);
   const size_t ni = (size_t)h->n_inst;
-  if ((rc = ac_upload(h, &h->d_R, desc->R_val, ni * P.nR)) != SPICEY_OK) return fail(rc);
+  {
+    std::vector<double> rinv(ni * (size_t)P.nR);
+    for (size_t i = 0; i < rinv.size(); i++) rinv[i] = 1.0 / desc->R_val[i];
+    if ((rc = ac_upload(h, &h->d_R, rinv.data(), rinv.size())) != SPICEY_OK) return fail(rc);
+  }
   if ((rc = ac_upload(h, &h->d_C, desc->C_val, ni * P.nC)) != SPICEY_OK) return fail(rc);
   if ((rc = ac_upload(h, &h->d_L, desc->L_val, ni * P.nL)) != SPICEY_OK) return fail(rc);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -189,7 +193,7 @@ extern "C" int32_t spicey_ac_run(SpiceyAcHandle *h, int64_t n_freq, const double
     ACCHK(h, hipMemcpyAsync(d_f, freqs, (size_t)n_freq * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (P.nV > 0) ACCHK(h, hipMemcpyAsync(d_ph, vph, (size_t)h->n_inst * P.nV * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     SpiceyAcRun R{};
-    R.R_val = h->d_R; R.C_val = h->d_C; R.L_val = h->d_L;
+    R.R_inv = h->d_R; R.C_val = h->d_C; R.L_val = h->d_L;
     R.freqs = d_f; R.vph = d_ph; R.out_v = d_ov; R.out_i = d_oi; R.gW = d_gW; R.status = d_status;
     R.n_freq = n_freq; R.n_inst = h->n_inst;
     ACCHK(h, hipEventRecord(h->ev0, h->stream));

@@ -15,7 +15,8 @@
 #define SPICEY_ERR_COMPLEX_DIV_CODE 5
 
 struct SpiceyAcRun {
-  const double *R_val, *C_val, *L_val;  // [n_inst][n<kind>]
+  const double *R_inv, *C_val, *L_val;  // [n_inst][n<kind>]; R_inv = 1 / R, formed once per handle on the host (the same IEEE
+                                        // quotient the reference forms at every frequency, simulateAC.ts:39-41)
   const double *freqs;                  // [n_freq]
   const double *vph;                    // [n_inst][nV][2] source phasors
   double *out_v;                        // [n_inst][n_freq][nOut][2]
@@ -56,7 +57,7 @@ struct AcPhases {
   }
   // admittance of static-stamp slot idx: [1/R | j w C | 1/(j w L) | 1] (simulateAC.ts:38-55)
   SPICEY_HD SpiceyCx admittance(uint32_t idx) const {
-    if (idx < (uint32_t)P.nR) return SpiceyCx{1.0 / R.R_val[inst * P.nR + idx], 0.0};
+    if (idx < (uint32_t)P.nR) return SpiceyCx{R.R_inv[inst * P.nR + idx], 0.0};
     idx -= P.nR;
     if (idx < (uint32_t)P.nC) return SpiceyCx{0.0, w * R.C_val[inst * P.nC + idx]};
     idx -= P.nC;

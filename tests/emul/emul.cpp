@@ -252,7 +252,9 @@ extern "C" int32_t spicey_emul_ac(const SpiceyDesc *d, int32_t T, int64_t n_freq
   const size_t slots = (size_t)d->n_inst * (size_t)n_freq;
   std::vector<int32_t> status(slots + 1);
   SpiceyAcRun R{};
-  R.R_val = d->R_val; R.C_val = d->C_val; R.L_val = d->L_val;
+  std::vector<double> rinv((size_t)d->n_inst * (size_t)d->nR);
+  for (size_t i2 = 0; i2 < rinv.size(); i2++) rinv[i2] = 1.0 / d->R_val[i2];
+  R.R_inv = rinv.data(); R.C_val = d->C_val; R.L_val = d->L_val;
   R.freqs = freqs; R.vph = vph; R.out_v = out_v; R.out_i = out_i; R.gW = nullptr; R.status = status.data();
   R.n_freq = n_freq; R.n_inst = d->n_inst;
   std::vector<SpiceyCx> W((size_t)P.nW + 1);
