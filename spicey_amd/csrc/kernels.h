@@ -17,8 +17,9 @@ int spicey_v2_rmax(int threads, bool packed = false);
 int spicey_v2_nsv(int threads, bool packed = false);
 int spicey_v2_nel(int threads, bool packed = false);
 int spicey_v2_max_threads(int K);
-hipError_t spicey_launch_tran_v2(const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, int K, int grid, int threads,
-                                 hipStream_t st, bool packed = false);
+// (Ph / Qh: host copies for the launch geometry; P / Q / R: the same structs in DEVICE memory — the kernel reads them by scalar loads)
+hipError_t spicey_launch_tran_v2(const SpiceyProg &Ph, const SpiceyResident &Qh, const SpiceyProg *P, const SpiceyResident *Q, const SpiceyRun *R, int K, int grid,
+                                 int threads, hipStream_t st, bool packed = false);
 
 // group mode: R.wgs_per_group workgroups per K instances, workspace in global memory (large circuits)
 hipError_t spicey_launch_tran_grp(const SpiceyProg &P, const SpiceyRun &R, int K, int n_groups, int threads, hipStream_t st);

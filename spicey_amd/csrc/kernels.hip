@@ -238,6 +238,19 @@ struct GpuExecV2 {
   unsigned long long *prof;  // LDS accumulators [SPICEY_PH_SLOTS] when profiling, else null
   Regs rr;
   __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
+  // the argument structs live in global memory; a phase sees them through an address the compiler cannot trace back, so
+  // the fields it uses are scalar-loaded inside the phase instead of being kept (and spilled) around the whole time loop
+  // (returned BY VALUE: a copy through a constant-address-space pointer, so that the loads are scalar (s_load, scalar cache);
+  // after inlining only the fields the phase touches are fetched, the rest of the copy is dead)
+  template <class X>
+  __device__ __forceinline__ X fresh(const X &x) const {
+    typedef const X __attribute__((address_space(4))) *cptr;
+    cptr p = (cptr)(&x);
+    asm volatile("" : "+s"(p));
+    X v;
+    __builtin_memcpy(&v, p, sizeof(X));
+    return v;
+  }
   template <class R2>
   __device__ __forceinline__ R2 &regs(int) {
     return rr;
@@ -280,7 +293,11 @@ struct GpuExecV2 {
 };
 
 template <int K, int RMAX, int NSV, int NEL, int MAXT, int MINW>
-__global__ void __launch_bounds__(MAXT, MINW) spicey_tran_kernel_v2(SpiceyProg P, SpiceyResident Q, SpiceyRun R) {
+__global__ void __launch_bounds__(MAXT, MINW) spicey_tran_kernel_v2(const SpiceyProg *__restrict__ Pg, const SpiceyResident *__restrict__ Qg,
+                                                                    const SpiceyRun *__restrict__ Rg) {
+  const SpiceyProg &P = *Pg;
+  const SpiceyResident &Q = *Qg;
+  const SpiceyRun &R = *Rg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WgCtx<K> c;
   const int wg = (int)blockIdx.x;
@@ -326,7 +343,7 @@ __global__ void __launch_bounds__(MAXT, MINW) spicey_tran_kernel_v2(SpiceyProg P
 }
 
 template <int K, int RMAX, int NSV, int NEL, int MAXT, int MINW>
-hipError_t launch_v2_t(const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, int grid, int threads, size_t lds, hipStream_t st) {
+hipError_t launch_v2_t(const SpiceyProg *P, const SpiceyResident *Q, const SpiceyRun *R, int grid, int threads, size_t lds, hipStream_t st) {
   auto kern = spicey_tran_kernel_v2<K, RMAX, NSV, NEL, MAXT, MINW>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -429,9 +446,9 @@ int spicey_v2_nsv(int threads, bool packed) { return packed ? 6 : (threads <= 25
 int spicey_v2_nel(int threads, bool packed) { return packed ? 2 : (threads <= 256 ? 4 : (threads <= 512 ? 2 : 1)); }
 int spicey_v2_max_threads(int K) { return K == 1 ? 1024 : 256; }
 
-hipError_t spicey_launch_tran_v2(const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, int K, int grid, int threads,
-                                 hipStream_t st, bool packed) {
-  const size_t bytes = spicey_lds_bytes(P, K, true, Q.tail_n);
+hipError_t spicey_launch_tran_v2(const SpiceyProg &Ph, const SpiceyResident &Qh, const SpiceyProg *P, const SpiceyResident *Q, const SpiceyRun *R, int K, int grid,
+                                 int threads, hipStream_t st, bool packed) {
+  const size_t bytes = spicey_lds_bytes(Ph, K, true, Qh.tail_n);
   if (packed) {
     if (K == 1 && threads == 512) return launch_v2_t<1, 4, 6, 2, 512, 4>(P, Q, R, grid, threads, bytes, st);
     return hipErrorInvalidValue;

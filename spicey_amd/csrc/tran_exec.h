@@ -1037,49 +1037,69 @@ struct TranPhases2 {
   }
 };
 
+// The three argument structs hold ~110 pointers: kept in SGPRs across the time loop they overflow the 102 scalar registers
+// of a wave and the compiler parks them in VGPR lanes (round 1: 274 spilled SGPRs, 1 209 v_readlane in the kernel — 13 % of
+// its instructions).  Every phase therefore takes the structs through `ex.fresh()`: on the GPU they live in global memory and
+// `fresh` makes their address opaque for this phase, so the fields a phase needs are fetched by scalar loads inside it
+// (scalar cache) and are dead at its barrier; only a handful of loop-control scalars stay live around the loop.
 template <int K, int RMAX, int NSV, int NEL, class Exec>
 SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, WgCtx<K> &c, int wg) {
   const int T = ex.threads();
-  TranPhases<K> ph{P, R, c, T};
-  TranPhases2<K, RMAX, NSV, NEL> p2{P, R, c, T, 0u, 0u};
-  p2.set_remainders();
+  typedef TranPhases2<K, RMAX, NSV, NEL> Ph2;
+  uint32_t brem, zrem;
+  {
+    Ph2 p2{P, R, c, T, 0u, 0u};
+    p2.set_remainders();
+    brem = p2.brem; zrem = p2.zrem;
+  }
   typedef ResRegs<K, RMAX, NSV, NEL> Regs;
   ex.phase(SPICEY_PH_PRO, [&](int tid) {
+    const SpiceyProg Pf = ex.fresh(P); const SpiceyResident Qf = ex.fresh(Q); const SpiceyRun Rf = ex.fresh(R);
+    TranPhases<K> ph{Pf, Rf, c, T};
+    Ph2 p2{Pf, Rf, c, T, brem, zrem};
     if (tid == 0) { c.flags[0] = 0; c.flags[1] = 0; c.flags[2] = -1; }
     ph.p0_gstat(tid);
-    p2.load_resident(tid, Q, ex.template regs<Regs>(tid));
-    for (int i = tid; i < Q.tail_n * 64; i += T) {  // tail records -> LDS (16 bytes each; no task = all zero)
-      const int p = Q.tail_first + (i >> 6), lane = i & 63;
-      const bool have = (uint32_t)lane < P.ph_cnt[p];
-      const uint32_t *src = P.rec16 + ((size_t)P.ph_first[p] + (have ? lane : 0)) * 4;
+    p2.load_resident(tid, Qf, ex.template regs<Regs>(tid));
+    for (int i = tid; i < Qf.tail_n * 64; i += T) {  // tail records -> LDS (16 bytes each; no task = all zero)
+      const int p = Qf.tail_first + (i >> 6), lane = i & 63;
+      const bool have = (uint32_t)lane < Pf.ph_cnt[p];
+      const uint32_t *src = Pf.rec16 + ((size_t)Pf.ph_first[p] + (have ? lane : 0)) * 4;
       for (int w = 0; w < 4; w++) c.tail[(size_t)i * 4 + w] = have ? src[w] : 0u;
     }
   });
-  ex.phase(SPICEY_PH_PRO, [&](int tid) { ph.p1_static(tid); });
-  ex.phase(SPICEY_PH_PRO, [&](int tid) { p2.a0_initial(tid, ex.template regs<Regs>(tid)); });
+  ex.phase(SPICEY_PH_PRO, [&](int tid) { const SpiceyProg Pf = ex.fresh(P); const SpiceyRun Rf = ex.fresh(R); TranPhases<K> ph{Pf, Rf, c, T}; ph.p1_static(tid); });
+  ex.phase(SPICEY_PH_PRO, [&](int tid) { const SpiceyProg Pf = ex.fresh(P); const SpiceyRun Rf = ex.fresh(R); Ph2 p2{Pf, Rf, c, T, brem, zrem}; p2.a0_initial(tid, ex.template regs<Regs>(tid)); });
   unsigned long long solves = 0;
   int32_t code = 0;
   int64_t err_step = 0;
   int32_t err_iter = 0;
   if (c.flags[1]) { code = 1; }
+  // loop control: a handful of scalars
   const int nL = P.nLevels;
+  const int nS = P.nS;
+  const int64_t steps = R.steps;
+  const int dbg_empty = R.debug_empty_phases;
   // which phases have work: kept in a scalar mask so that the phase loop issues no loads
   unsigned long long active = 0, smask = 0;
   for (int p = 0; p < 2 * nL && p < 64; p++) {
     if (SPICEY_UNIFORM((int)P.ph_cnt[p]) != 0) active |= 1ull << p;
     if (SPICEY_UNIFORM((int)Q.st_cnt[p]) != 0) smask |= 1ull << p;
   }
-  const int u_end = Q.tail_n > 0 ? Q.tail_first : nL;
-  const int k_begin = Q.tail_n > 0 ? Q.tail_first + Q.tail_n : nL;
+  const int tail_n = Q.tail_n, tail_first = Q.tail_first;
+  const int u_end = tail_n > 0 ? tail_first : nL;
+  const int k_begin = tail_n > 0 ? tail_first + tail_n : nL;
   const bool z_pre = K == 1 && k_begin < 2 * nL;  // Z's parameter fetch rides on the last backward phase
   // No diodes and no switches: the matrix of every step is the matrix of step 0 (dt is fixed within a run), so its
   // factors stay in W and later steps run the right-hand-side column only.  Same operands, same order: the results
   // are bit-identical to refactoring (SURVEY.md §8(d) "solve-only" rate; the reference itself never reuses).
-  const bool linear = P.nD == 0 && P.nS == 0 && P.nDynEnt == 0 && !R.no_reuse;
-  for (int64_t step = 0; step <= R.steps && code == 0; step++) {
+  const bool linear = P.nD == 0 && nS == 0 && P.nDynEnt == 0 && !R.no_reuse;
+  for (int64_t step = 0; step <= steps && code == 0; step++) {
     int iter = 0;
     for (;;) {
       ex.phase(SPICEY_PH_B, [&](int tid) {
+        const SpiceyProg Pf = ex.fresh(P);
+        const SpiceyRun Rf = ex.fresh(R);
+        Ph2 p2{Pf, Rf, c, T, brem, zrem};
         // the next step's source values ride on B (a long phase with few live registers): fetched first, parked in
         // LDS last; Z moves them into place
         double sn = K == 1 ? p2.z_src_fetch(tid, step) : 0.0;
@@ -1088,12 +1108,14 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
         SPICEY_SCHED_FENCE;
         if (K == 1) p2.z_src_park(tid, sn);
       });
-      for (int d = 0; d < R.debug_empty_phases; d++) ex.phase(SPICEY_PH_S, [&](int) {});  // diagnostics: cost of a bare phase
+      for (int d = 0; d < dbg_empty; d++) ex.phase(SPICEY_PH_S, [&](int) {});  // diagnostics: cost of a bare phase
       // factor levels [0, u_end) | tail [u_end, k_begin) by one wave | backward levels [k_begin, 2 nL)
       for (int p = 0; p < u_end; p++) {
         if (p < 64 ? !((active >> p) & 1) : P.ph_cnt[p] == 0) continue;
         ex.phase(SPICEY_PH_U0 + (p < 30 ? p : 30), [&](int tid) {
-          spicey_uk_phase<K, RMAX, NSV, NEL, false>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true, linear && step > 0);
+          const SpiceyProg Pf = ex.fresh(P);
+          const SpiceyResident Qf = ex.fresh(Q);
+          spicey_uk_phase<K, RMAX, NSV, NEL, false>(Pf, Qf, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true, linear && step > 0);
         });
       }
       if (k_begin > u_end) {
@@ -1104,14 +1126,17 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
                         r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3];
                       },
                       [&](int, int lvl, const uint32_t *r) {
-                        if (u_end + lvl < nL) spicey_exec_rec16<K, false>(c, P.ovf16, r[0], r[1], r[2], r[3], (linear && step > 0) ? (uint32_t)P.nLU : 0u);
-                        else spicey_exec_rec16<K, true>(c, P.ovf16, r[0], r[1], r[2], r[3]);
+                        const SpiceyProg Pf = ex.fresh(P);
+                        if (u_end + lvl < nL) spicey_exec_rec16<K, false>(c, Pf.ovf16, r[0], r[1], r[2], r[3], (linear && step > 0) ? (uint32_t)Pf.nLU : 0u);
+                        else spicey_exec_rec16<K, true>(c, Pf.ovf16, r[0], r[1], r[2], r[3]);
                       });
       }
       for (int p = k_begin; p < 2 * nL - 1; p++) {
         const int l = 2 * nL - 1 - p;
         ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) {
-          spicey_uk_phase<K, RMAX, NSV, NEL, true>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
+          const SpiceyProg Pf = ex.fresh(P);
+          const SpiceyResident Qf = ex.fresh(Q);
+          spicey_uk_phase<K, RMAX, NSV, NEL, true>(Pf, Qf, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
         });
       }
       // the last backward phase (level 0) is peeled: it also issues Z's parameter fetch.  (Every path through the
@@ -1119,20 +1144,23 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
       if (k_begin < 2 * nL) {
         const int p = 2 * nL - 1;
         ex.phase(SPICEY_PH_K0, [&](int tid) {
-          spicey_uk_phase<K, RMAX, NSV, NEL, true>(P, Q, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
+          const SpiceyProg Pf = ex.fresh(P);
+          const SpiceyResident Qf = ex.fresh(Q);
+          spicey_uk_phase<K, RMAX, NSV, NEL, true>(Pf, Qf, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
           SPICEY_SCHED_FENCE;  // after the tasks, not among them: their registers are free by now
-          if (K == 1) p2.z_prefetch(tid, step, 0, ex.template regs<Regs>(tid));
+          if (K == 1) { const SpiceyRun Rf = ex.fresh(R); Ph2 p2{Pf, Rf, c, T, brem, zrem}; p2.z_prefetch(tid, step, 0, ex.template regs<Regs>(tid)); }
         });
       } else if (K == 1) {
+        Ph2 p2{P, R, c, T, brem, zrem};
         p2.z_prefetch_none(ex.template regs<Regs>(0));
       }
       if (c.flags[1]) { code = 1; err_step = step; err_iter = iter; break; }
-      if (P.nS == 0) break;
-      ex.phase(SPICEY_PH_S, [&](int tid) { ph.s_switches(tid); });
+      if (nS == 0) break;
+      ex.phase(SPICEY_PH_S, [&](int tid) { const SpiceyProg Pf = ex.fresh(P); const SpiceyRun Rf = ex.fresh(R); TranPhases<K> ph{Pf, Rf, c, T}; ph.s_switches(tid); });
       const int switched = c.flags[0];
       if (!switched || iter == SPICEY_MAX_ITER - 1) break;
       iter++;
-      ex.phase(SPICEY_PH_A, [&](int tid) { p2.a_reiterate(tid); });
+      ex.phase(SPICEY_PH_A, [&](int tid) { const SpiceyProg Pf = ex.fresh(P); const SpiceyRun Rf = ex.fresh(R); Ph2 p2{Pf, Rf, c, T, brem, zrem}; p2.a_reiterate(tid); });
     }
     if (code) break;
     {
@@ -1141,19 +1169,23 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
       solves += (unsigned long long)(iter + 1) * (unsigned long long)nvalid;
     }
     ex.phase(SPICEY_PH_Z, [&](int tid) {
-      if (tid == 0 && R.iters)
+      const SpiceyRun Rf = ex.fresh(R);
+      const SpiceyProg Pf = ex.fresh(P);
+      Ph2 p2{Pf, Rf, c, T, brem, zrem};
+      if (tid == 0 && Rf.iters)
         for (int k = 0; k < K; k++)
-          if (c.valid[k]) R.iters[(size_t)c.inst[k] * (size_t)(R.steps + 1) + (size_t)step] = iter + 1;
+          if (c.valid[k]) Rf.iters[(size_t)c.inst[k] * (size_t)(steps + 1) + (size_t)step] = iter + 1;
       p2.z_record(tid, step, ex.template regs<Regs>(tid), z_pre);
     });
   }
   ex.phase(SPICEY_PH_PRO, [&](int tid) {
     if (tid == 0) {
-      R.status[wg * 4 + 0] = code;
-      R.status[wg * 4 + 1] = c.flags[2];
-      R.status[wg * 4 + 2] = (int32_t)err_step;
-      R.status[wg * 4 + 3] = err_iter;
-      R.solves[wg] = solves;
+      const SpiceyRun Rf = ex.fresh(R);
+      Rf.status[wg * 4 + 0] = code;
+      Rf.status[wg * 4 + 1] = c.flags[2];
+      Rf.status[wg * 4 + 2] = (int32_t)err_step;
+      Rf.status[wg * 4 + 3] = err_iter;
+      Rf.solves[wg] = solves;
     }
   });
 }

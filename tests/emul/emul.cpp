@@ -44,6 +44,8 @@ struct SeqExec {
   void front_post(unsigned int *, unsigned int) {}
   void front_wait(unsigned int *, unsigned int) {}
   void mark(int) {}
+  template <class X>
+  X fresh(const X &x) const { return x; }
   int local_threads() const { return chain ? T / 2 : T; }
   void sync() {}
   template <class F>
