@@ -47,7 +47,9 @@ struct FrontsRun {
   }
 
   // ---- assembly into A (row stride lda; LDS or global) ----------------------------------------------------
-  SPICEY_HD void assemble(const SpiceyFront &F, double *A, int lda) const {
+  // own part: zero, entries + right-hand side taken over from W (final once the levels below the cut are done: this
+  // part runs BEFORE the front waits for children of other workgroups, inside what would be idle time)
+  SPICEY_HD void assemble_own(const SpiceyFront &F, double *A, int lda) const {
     const int nel = F.Mp * lda;
     ex.wg_phase([&](int t) {
       SPICEY_NOUNROLL
@@ -77,8 +79,16 @@ struct FrontsRun {
       for (int r = F.p + t; r < F.Pp; r += T) A[(size_t)r * lda + r] = 1.0;  // identity padding of the pivot block
     });
     ex.mark(SPICEY_PH_U0 + 17);
-    for (uint32_t ci = 0; ci < F.child_n; ci++) {  // extend-add, children in a fixed order
-      const SpiceyFront C = P.fr[P.fr_child[F.child0 + ci]];
+  }
+  // children's contribution blocks, in a fixed order; a child of another workgroup is waited for right before its turn
+  SPICEY_HD void assemble_children(const SpiceyFront &F, double *A, int lda, unsigned int epoch) const {
+    for (uint32_t ci = 0; ci < F.child_n; ci++) {  // extend-add
+      const uint32_t cid = P.fr_child[F.child0 + ci];
+      if (foreign(cid)) {
+        ex.front_wait(fl + cid, epoch);
+        ex.mark(SPICEY_PH_U0 + 4);
+      }
+      const SpiceyFront C = P.fr[cid];
       const double *Ac = FW + C.off;
       const uint32_t *rel = P.fr_rel + C.rel0;
       ex.wg_phase([&](int t) {
@@ -384,22 +394,19 @@ struct FrontsRun {
     for (uint32_t s = R.fs_first[w]; s < R.fs_first[w + 1]; s++) {
       const uint32_t f = R.fs_list[s];
       const SpiceyFront F = P.fr[f];
-      for (uint32_t ci = 0; ci < F.child_n; ci++) {
-        const uint32_t c = P.fr_child[F.child0 + ci];
-        if (foreign(c)) ex.front_wait(fl + c, epoch);
-      }
-      ex.mark(SPICEY_PH_U0 + 4);  // waiting for children of other workgroups
       if (fits_lds(F)) {
         double *A = ex.lds();
         const int lda = F.Mp + SPICEY_FRONT_LDS_PAD;
-        assemble(F, A, lda);
+        assemble_own(F, A, lda);
+        assemble_children(F, A, lda, epoch);
         ex.mark(SPICEY_PH_U0 + 5);
         factor_lds(F, A, lda, A + (size_t)F.Mp * lda);
         ex.mark(SPICEY_PH_U0 + 6);
         store_lds_front(F, A, lda);
         ex.mark(SPICEY_PH_U0 + 7);
       } else {
-        assemble(F, FW + F.off, F.ld);
+        assemble_own(F, FW + F.off, F.ld);
+        assemble_children(F, FW + F.off, F.ld, epoch);
         ex.mark(SPICEY_PH_U0 + 8);
         factor_global(F);
         ex.mark(SPICEY_PH_U0 + 9);

@@ -5,6 +5,7 @@
 
 #include "program.h"
 
+#define SPICEY_GRP_SYNC_WORDS 320  // uint32 words of barrier state per group: [0] flat counter, [1] abort, [16..] XCD census / arrivals / top / generation
 #define SPICEY_LDS_MAX 163840  // 160 KiB per CU on MI355X (MI355X_MICROARCH.md "Chip-level parameters")
 
 size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds, int tail_n = 0);

@@ -175,7 +175,57 @@ struct GpuGroupExec {
       __syncthreads();
     }
   }
+  // XCD-hierarchical form (MI355X_MICROARCH.md, price list row "barrier-xcd"): the L2 is shared inside an XCD, so ONE
+  // write-back per XCD publishes the stores of all its workgroups.  Each workgroup drains its stores and arrives on its
+  // XCD's counter; the last arriver of an XCD releases (buffer_wbl2) and arrives on the top counter; the last XCD
+  // publishes the generation; everybody polls the generation, then acquires.  Which workgroups share an XCD is read
+  // from HW_REG_XCC_ID by a census at kernel start (census()): nothing is assumed about placement.
+  unsigned int *hb;       // this group's hierarchical-barrier words: [x * 16] members of XCD x, [128 + x * 16] arrivals, [256] top, [272] generation
+  unsigned int hep, my_x, n_mine, n_xcd;
+  __device__ __forceinline__ void census() {
+    unsigned int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    my_x = x & 7u;
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(hb + my_x * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flat_barrier();
+    n_mine = 0; n_xcd = 0;
+    for (unsigned int i = 0; i < 8; i++) {
+      const unsigned int m = __hip_atomic_load(hb + i * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      n_xcd += m != 0u ? 1u : 0u;
+      if (i == my_x) n_mine = m;
+    }
+    n_mine = (unsigned int)__builtin_amdgcn_readfirstlane((int)n_mine);
+    n_xcd = (unsigned int)__builtin_amdgcn_readfirstlane((int)n_xcd);
+    hep = 0;
+  }
   __device__ __forceinline__ void barrier() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    hep++;
+    if (threadIdx.x == 0) {
+      const unsigned int a = __hip_atomic_fetch_add(hb + 128 + my_x * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a + 1u == hep * n_mine) {  // last workgroup of this XCD: its write-back covers the whole XCD's L2
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(hb + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1u == hep * n_xcd) __hip_atomic_store(hb + 272, hep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      unsigned int spins = 0;
+      while ((int)(__hip_atomic_load(hb + 272, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - hep) < 0) {
+        if (++spins > (1u << 22) || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) bad = true;
+  }
+  // the flat form (one counter, every workgroup releases): used once, for the census
+  __device__ __forceinline__ void flat_barrier() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     epoch++;
@@ -227,8 +277,10 @@ __global__ void __launch_bounds__(FRONTS ? 512 : 1024) spicey_tran_kernel_grp(Sp
     c.valid[k] = in < R.n_inst;
     c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
   }
-  GpuGroupExec ex{G, wgi, R.grp_sync + (size_t)grp * 4, R.grp_sync + (size_t)grp * 4 + 1, 0u, false, (double *)smem,
-                  R.prof ? R.prof + (size_t)blockIdx.x * SPICEY_PH_SLOTS : nullptr, (unsigned long long)wall_clock64()};
+  unsigned int *gs = R.grp_sync + (size_t)grp * SPICEY_GRP_SYNC_WORDS;
+  GpuGroupExec ex{G, wgi, gs, gs + 1, 0u, false, (double *)smem,
+                  R.prof ? R.prof + (size_t)blockIdx.x * SPICEY_PH_SLOTS : nullptr, (unsigned long long)wall_clock64(), gs + 16, 0u, 0u, 1u, 1u};
+  ex.census();
   spicey_tran_run<K, FRONTS>(ex, P, R, c, grp);
 }
 

@@ -289,7 +289,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
     h->G = G;
     if (G > 1) {
       const unsigned int *nou = nullptr;
-      if ((rc = upload(h, &h->d_gsync, nou, (size_t)h->grid * 4)) != SPICEY_OK) return fail(rc);
+      if ((rc = upload(h, &h->d_gsync, nou, (size_t)h->grid * SPICEY_GRP_SYNC_WORDS)) != SPICEY_OK) return fail(rc);
       const int32_t *noi = nullptr;
       if ((rc = upload(h, &h->d_gflags, noi, (size_t)h->grid * 4)) != SPICEY_OK) return fail(rc);
     }
@@ -392,7 +392,7 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
     h->run_args = R;
     HIPCHK(h, hipMemcpyAsync(h->d_Rstruct, &h->run_args, sizeof(SpiceyRun), hipMemcpyHostToDevice, st));
   }
-  if (h->G > 1) HIPCHK(h, hipMemsetAsync(h->d_gsync, 0, (size_t)h->grid * 4 * sizeof(unsigned int), st));
+  if (h->G > 1) HIPCHK(h, hipMemsetAsync(h->d_gsync, 0, (size_t)h->grid * SPICEY_GRP_SYNC_WORDS * sizeof(unsigned int), st));
   HIPCHK(h, hipEventRecord(h->ev0, st));  // (argument upload and flag resets stay outside the timed kernel)
   if (h->interp == 2) {
     HIPCHK(h, spicey_launch_tran_v2(h->dprog, h->dres, h->d_Pstruct, h->d_Qstruct, h->d_Rstruct, h->K, h->grid, h->T, st, h->packed));

@@ -675,7 +675,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   if (Lc < 0) {
     // automatic: only where the long single-pivot chains of the top separators dominate (large, nonlinear circuits;
     // a linear circuit reuses its factors and keeps the task lists)
-    Lc = (nD + nS > 0 && nLU >= 40000 && nLevels > 24 && !hp.structurally_singular) ? 12 : 0;
+    Lc = (nD + nS > 0 && nLU >= 40000 && nLevels > 24 && !hp.structurally_singular) ? 10 : 0;
     if (const char *e = getenv("SPICEY_FRONT_CUT")) Lc = atoi(e);  // experiments
   }
   if (Lc >= nLevels || hp.structurally_singular) Lc = 0;
