@@ -329,29 +329,35 @@ struct FrontsRun {
       Db[e] = r < F.p ? A[(size_t)r * F.ld + cc] : (r == cc ? 1.0 : 0.0);
     }
   }
-  SPICEY_HD void solve(const SpiceyFront &F) const {
+  // Own data first (right-hand side after the forward sweep, last diagonal block): this part does not need the ancestors'
+  // unknowns and runs BEFORE the front waits for its parent's workgroup; then the boundary product straight from W.
+  SPICEY_HD void solve(const SpiceyFront &F, bool wait_parent, unsigned int epoch) const {
     const double *A = FW + F.off;
     double *lds = ex.lds();
     double *xs = lds, *tt = xs + F.Mp, *part = tt + F.Pp, *Db = part + (size_t)F.Pp * 4;  // Db: 16 x 16 diagonal block
     const uint32_t *bnd = P.fr_bnd + F.bnd0;
     ex.wg_phase([&](int t) {
       SPICEY_NOUNROLL
-      for (int j = t; j < F.q; j += T) xs[F.Pp + j] = W[(size_t)P.nLU + bnd[j]];
-      SPICEY_NOUNROLL
       for (int i = t; i < F.Pp; i += T) tt[i] = i < F.p ? A[(size_t)i * F.ld + F.Mp] : 0.0;
+      load_db(F, A, Db, t, F.Pp - SPICEY_FB);
     });
+    if (wait_parent) ex.front_wait(fl + P.nFronts + F.parent, epoch);
+    ex.mark(SPICEY_PH_U0 + 10);
     ex.wg_phase([&](int t) {  // t = y_P - U_PB x_B: four partial sums per row, combined in a fixed order
       SPICEY_NOUNROLL
       for (int it = t; it < F.p * 4; it += T) {
         const int i = it >> 2, sg = it & 3;
         const double *row = A + (size_t)i * F.ld + F.Pp;
+        const double *xW = W + (size_t)P.nLU;
         double s = 0.0;
         int j = sg;
-        for (; j + 12 < F.q; j += 16) {  // four loads in flight; the sum keeps its order
+        for (; j + 12 < F.q; j += 16) {  // four (index -> unknown) chains and four matrix loads in flight; the sum keeps its order
+          const uint32_t b0 = bnd[j], b1 = bnd[j + 4], b2 = bnd[j + 8], b3 = bnd[j + 12];
           const double r0 = row[j], r1 = row[j + 4], r2 = row[j + 8], r3 = row[j + 12];
-          s = fma(r0, xs[F.Pp + j], s); s = fma(r1, xs[F.Pp + j + 4], s); s = fma(r2, xs[F.Pp + j + 8], s); s = fma(r3, xs[F.Pp + j + 12], s);
+          const double x0 = xW[b0], x1 = xW[b1], x2 = xW[b2], x3 = xW[b3];
+          s = fma(r0, x0, s); s = fma(r1, x1, s); s = fma(r2, x2, s); s = fma(r3, x3, s);
         }
-        for (; j < F.q; j += 4) s = fma(row[j], xs[F.Pp + j], s);
+        for (; j < F.q; j += 4) s = fma(row[j], xW[bnd[j]], s);
         part[it] = s;
       }
     });
@@ -359,7 +365,6 @@ struct FrontsRun {
     ex.wg_phase([&](int t) {
       SPICEY_NOUNROLL
       for (int i = t; i < F.p; i += T) tt[i] -= (part[4 * i] + part[4 * i + 1]) + (part[4 * i + 2] + part[4 * i + 3]);
-      load_db(F, A, Db, t, b_last);
     });
     for (int b0 = b_last; b0 >= 0; b0 -= SPICEY_FB) {
       // one wave, 16 lanes in lockstep: step s solves x of row k = 15 - s and removes it from the rows above it
@@ -420,9 +425,7 @@ struct FrontsRun {
     for (uint32_t s = R.fs_first[w + 1]; s > R.fs_first[w]; s--) {
       const uint32_t f = R.fs_list[s - 1];
       const SpiceyFront F = P.fr[f];
-      if (F.parent >= 0 && foreign((uint32_t)F.parent)) ex.front_wait(fl + P.nFronts + F.parent, epoch);
-      ex.mark(SPICEY_PH_U0 + 10);
-      solve(F);
+      solve(F, F.parent >= 0 && foreign((uint32_t)F.parent), epoch);
       ex.mark(SPICEY_PH_U0 + 11);
       bool any = false;
       for (uint32_t ci = 0; ci < F.child_n; ci++) any = any || foreign(P.fr_child[F.child0 + ci]);
