@@ -92,6 +92,7 @@ typedef struct SpiceyOptions {
   int32_t debug;         /* diagnostics: bit 0 = no tail merge; bit 1 = refactor every step even for linear circuits;
                             bit 2 = plain CSR numbering of the L+U entries (no LDS-bank-aware slot-major numbering);
                             bit 3 = dense fronts above 64 rows take the staged (global-memory) path even if they fit LDS;
+                            bit 4 = AC: never use the resident sweep (one workgroup per (instance, frequency) always);
                             bits 8.. = extra empty phases per solve */
   int32_t wgs_per_inst;  /* global-workspace path: workgroups (CUs) cooperating on one instance; 0 auto, 1 = none */
   int32_t front_cut;     /* dense fronts (large instances): pivots of elimination-tree level >= front_cut are factored as

@@ -28,6 +28,32 @@ struct GpuAcExec {
   }
 };
 
+template <class Regs>
+struct GpuAcExecRes {
+  Regs rr;
+  __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
+  template <class R2>
+  __device__ __forceinline__ R2 &regs(int) { return rr; }
+  template <class F>
+  __device__ __forceinline__ void phase(int, F f) {
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));  // (keeps per-thread addresses from being hoisted out of the frequency loop)
+    f(tid);
+    __syncthreads();
+  }
+};
+
+// Resident sweep: blockIdx.x = instance * n_chunk + c; the workgroup runs frequencies c, c + n_chunk, ... of its instance
+// with the task records and the frequency-independent stamp parts in registers (ac_exec.h).
+template <int RMAX, int NSE>
+__global__ void __launch_bounds__(512) spicey_ac_kernel_res(SpiceyProg P, SpiceyResident Q, SpiceyAcRun R, int n_chunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int32_t flags[2];
+  GpuAcExecRes<AcResRegs<RMAX, NSE>> ex;
+  spicey_ac_sweep_resident<RMAX, NSE>(ex, P, Q, R, (SpiceyCx *)smem, flags, (size_t)(blockIdx.x / (unsigned)n_chunk), (int64_t)(blockIdx.x % (unsigned)n_chunk),
+                                      (int64_t)n_chunk);
+}
+
 template <bool LDS>
 __global__ void __launch_bounds__(1024) spicey_ac_kernel(SpiceyProg P, SpiceyAcRun R) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -40,8 +66,19 @@ __global__ void __launch_bounds__(1024) spicey_ac_kernel(SpiceyProg P, SpiceyAcR
 
 }  // namespace
 
+// resident sweep geometry: <= 512 threads (256 VGPRs, no spills): 12 task records, 10 entries' stamp parts per thread
+#define SPICEY_AC_RMAX 12
+#define SPICEY_AC_NSE 10
+
 struct SpiceyAcHandle {
   HostProgram hp;
+  HostResident hres;       // resident layout of the 16-bit records (batched sweeps)
+  SpiceyResident dres{};
+  void *d_res = nullptr;
+  bool resident_ok = false;
+  int ncu = 256;
+  int last_mode = 0;       // 1 = one workgroup per (instance, frequency), 2 = resident sweep
+  int Tres = 512;          // threads of the resident sweep's workgroups
   SpiceyProg dprog{};
   SpiceyOptions opt{};
   int n_inst = 0, T = 256, device = 0;
@@ -61,7 +98,7 @@ extern "C" const char *spicey_ac_last_error(SpiceyAcHandle *h) { return h ? h->e
 
 extern "C" void spicey_ac_destroy(SpiceyAcHandle *h) {
   if (!h) return;
-  void *ptrs[] = {h->d_blob, h->d_R, h->d_C, h->d_L};
+  void *ptrs[] = {h->d_blob, h->d_R, h->d_C, h->d_L, h->d_res};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -130,6 +167,18 @@ extern "C" int32_t spicey_ac_create(const SpiceyDesc *desc, const SpiceyOptions 
     return fail(SPICEY_ERR_HIP);
   }
   h->dprog = h->hp.bind(h->d_blob);
+  (void)hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+  // resident sweep for batches that outnumber the CUs: needs the LDS workspace, 16-bit records, and every entry in the
+  // NSE register slots of a thread
+  h->Tres = std::min(h->T, 512);
+  if (h->lds && P.has16 && P.nLU <= SPICEY_AC_NSE * h->Tres && (int)h->hp.ph_cnt.size() <= 254) {
+    spicey_build_resident(h->hp, h->Tres, SPICEY_AC_RMAX, h->hres, 0);
+    if (hipMalloc(&h->d_res, h->hres.blob.size()) == hipSuccess &&
+        hipMemcpy(h->d_res, h->hres.blob.data(), h->hres.blob.size(), hipMemcpyHostToDevice) == hipSuccess) {
+      h->dres = h->hres.bind(h->d_res);
+      h->resident_ok = true;
+    }
+  }
   const size_t ni = (size_t)h->n_inst;
   {
     std::vector<double> rinv(ni * (size_t)P.nR);
@@ -158,7 +207,10 @@ extern "C" int32_t spicey_ac_get_info(SpiceyAcHandle *h, SpiceyInfo *info) {
   info->lds_bytes = h->lds ? (int32_t)h->lds_bytes : 0;
   info->n_cur = h->hp.hdr.nR + h->hp.hdr.nC + h->hp.hdr.nL + h->hp.hdr.nV;
   info->n_out = h->hp.hdr.nOut;
-  info->interpreter = 1;
+  info->interpreter = h->last_mode == 2 ? 2 : 1;  // 2 = the last run used the resident sweep
+  info->resident_slots = h->resident_ok ? SPICEY_AC_RMAX : 0;
+  info->resident_tasks = h->hres.resident_tasks;
+  info->streamed_tasks = h->hres.streamed_tasks;
   info->wgs_per_inst = 1;
   info->program_bytes = (int64_t)h->hp.blob.size();
   return SPICEY_OK;
@@ -197,6 +249,19 @@ extern "C" int32_t spicey_ac_run(SpiceyAcHandle *h, int64_t n_freq, const double
     R.freqs = d_f; R.vph = d_ph; R.out_v = d_ov; R.out_i = d_oi; R.gW = d_gW; R.status = d_status;
     R.n_freq = n_freq; R.n_inst = h->n_inst;
     ACCHK(h, hipEventRecord(h->ev0, h->stream));
+    // batches that outnumber the CUs (one workgroup per CU at this LDS size): persistent workgroups, ~2 per CU, each
+    // keeping its share of the program in registers across its frequencies
+    const bool resident = h->resident_ok && !(h->opt.debug & 16) && slots > (size_t)2 * (size_t)h->ncu;
+    h->last_mode = resident ? 2 : 1;
+    if (resident) {
+      const int n_chunk = (int)std::min<int64_t>(n_freq, std::max<int64_t>(1, ((int64_t)2 * h->ncu + h->n_inst - 1) / h->n_inst));
+      auto kern = spicey_ac_kernel_res<SPICEY_AC_RMAX, SPICEY_AC_NSE>;
+      if (h->lds_bytes > 48 * 1024)
+        ACCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+      R.slot_base = 0;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(h->n_inst * n_chunk)), dim3(h->Tres), h->lds_bytes, h->stream, h->dprog, h->dres, R, n_chunk);
+      ACCHK(h, hipGetLastError());
+    } else
     for (size_t base = 0; base < slots; base += chunk) {
       const unsigned grid = (unsigned)std::min(chunk, slots - base);
       R.slot_base = (int64_t)base;

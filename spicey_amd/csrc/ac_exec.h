@@ -198,3 +198,207 @@ SPICEY_HD void spicey_ac_solve(Exec &ex, const SpiceyProg &P, const SpiceyAcRun 
     if (tid == 0) R.status[slot] = code;
   });
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Resident sweep: ONE persistent workgroup runs many frequencies of one instance.  What does not depend on the frequency
+// is fetched once and kept in registers — the step the transient kernel took from v1 to v2:
+//   * the factor / backward task records (16-byte records with 16-bit indices, the layout of spicey_build_resident: every
+//     (wave, slot) chunk belongs to one phase; phases that do not fit the RMAX slots stay streamed from P.rec16);
+//   * of every entry e = tid + j T the frequency-independent parts: gr = sum of +-1/R and +-1 (source incidences),
+//     gc = sum of +-C, so that the stamp of a frequency is (gr, w gc) — the reference adds the admittances one by one
+//     (simulateAC.ts:38-55): the imaginary part differs by the rounding of w (C1 + C2) against w C1 + w C2, ~1e-16 relative.
+//     Entries with an inductor stamp keep the exact per-stamp path (guards of :47-55 included).
+// The backward substitution uses the ROW-oriented records (x_k = (y_k - sum U_kb x_b) / u_kk), so no scaling phase.
+template <int RMAX, int NSE>
+struct AcResRegs {
+  uint32_t w0[RMAX], w1[RMAX], w2[RMAX], w3[RMAX];
+  uint32_t phv[RMAX / 4];  // phase of every slot, one byte each (0xFF = unused); wave-uniform
+  double gr[NSE], gc[NSE];
+  uint32_t ef;           // 3 bits per entry slot: bit 0 leaf diagonal (invert as stamped), bit 1 has an inductor stamp (generic path), bit 2 = the slot holds an entry
+  uint32_t rowsrc;       // bit j: row tid + j T has source contributions (its right-hand side is not zero)
+};
+
+template <class Exec, int RMAX, int NSE>
+struct AcResident {
+  typedef AcResRegs<RMAX, NSE> Regs;
+  const SpiceyProg &P;
+  const SpiceyResident &Q;
+  const SpiceyAcRun &R;
+  SpiceyCx *W;
+  int32_t *flags;
+  int T;
+  size_t inst;
+
+  SPICEY_HD void load(int tid, Regs &rr, const AcPhases<Exec> &gen) const {
+    for (int s = 0; s < RMAX; s++) {
+      const bool have = s < Q.rmax;
+      const uint32_t *src = Q.res + ((size_t)(have ? s : 0) * T + tid) * 4;
+      rr.w0[s] = have ? src[0] : 0u; rr.w1[s] = have ? src[1] : 0u; rr.w2[s] = have ? src[2] : 0u; rr.w3[s] = have ? src[3] : 0u;
+    }
+    for (int s4 = 0; s4 < RMAX / 4; s4++) {
+      uint32_t pk = 0;
+      for (int b = 0; b < 4; b++) {
+        const int s = s4 * 4 + b;
+        const int ph = s < Q.rmax ? Q.res_phase[(size_t)(tid >> 6) * Q.rmax + s] : -1;
+        pk |= (uint32_t)(ph < 0 ? 0xff : (ph & 0xff)) << (8 * b);
+      }
+      rr.phv[s4] = pk;
+    }
+    rr.ef = 0u;
+    for (int j = 0; j < NSE; j++) {
+      const int e = tid + j * T;
+      double gr = 0.0, gc = 0.0;
+      uint32_t f = 0u;
+      if (e < P.nLU) {
+        f = 4u | (uint32_t)(P.ent_flag[e] & 1);
+        for (uint32_t k = P.stat_ptr[e]; k < P.stat_ptr[e + 1]; k++) {
+          const uint32_t ix = P.stat_idx[k], idx = SPICEY_IDX(ix);
+          if (idx >= (uint32_t)(P.nR + P.nC) && idx < (uint32_t)(P.nR + P.nC + P.nL)) { f |= 2u; continue; }
+          const SpiceyCx g = idx < (uint32_t)P.nR || idx >= (uint32_t)(P.nR + P.nC + P.nL) ? gen.admittance(idx)
+                                                                                           : SpiceyCx{0.0, R.C_val[inst * P.nC + (idx - P.nR)]};
+          if (ix & SPICEY_NEG) { gr -= g.re; gc -= g.im; } else { gr += g.re; gc += g.im; }
+        }
+      }
+      rr.gr[j] = gr; rr.gc[j] = gc; rr.ef |= f << (3 * j);
+    }
+    rr.rowsrc = 0u;
+    const uint32_t oV = (uint32_t)(P.nC + P.nL);
+    for (int j = 0; j < 32; j++) {
+      const int r = tid + j * T;
+      if (r >= P.n) break;
+      for (uint32_t k = P.rhs_ptr[r]; k < P.rhs_ptr[r + 1]; k++) {
+        const uint32_t u = SPICEY_IDX(P.rhs_idx[k]);
+        if (u >= oV && u < oV + (uint32_t)P.nV) rr.rowsrc |= 1u << j;
+      }
+    }
+  }
+
+  SPICEY_HD void stamp(int tid, const Regs &rr, const AcPhases<Exec> &gen) const {
+    const double w = gen.w;
+    SPICEY_UNROLL
+    for (int j = 0; j < NSE; j++) {
+      const uint32_t f = (rr.ef >> (3 * j)) & 7u;
+      if (!(f & 4u)) continue;
+      const int e = tid + j * T;
+      SpiceyCx v{rr.gr[j], w * rr.gc[j]};
+      if (f & 2u) {  // an inductor among the stamps: the reference's own sequence for this entry
+        v = SpiceyCx{0.0, 0.0};
+        for (uint32_t k = P.stat_ptr[e]; k < P.stat_ptr[e + 1]; k++) {
+          const uint32_t ix = P.stat_idx[k];
+          const SpiceyCx g = gen.admittance(SPICEY_IDX(ix));
+          v = (ix & SPICEY_NEG) ? cx_sub(v, g) : cx_add(v, g);
+        }
+      }
+      if (f & 1u) v = gen.pivot_inv(v);
+      W[e] = v;
+    }
+    SPICEY_NOUNROLL
+    for (int e = tid + NSE * T; e < P.nLU; e += T) {  // entries beyond the resident capacity
+      SpiceyCx v{0.0, 0.0};
+      for (uint32_t k = P.stat_ptr[e]; k < P.stat_ptr[e + 1]; k++) {
+        const uint32_t ix = P.stat_idx[k];
+        const SpiceyCx g = gen.admittance(SPICEY_IDX(ix));
+        v = (ix & SPICEY_NEG) ? cx_sub(v, g) : cx_add(v, g);
+      }
+      if (P.ent_flag[e] & 1) v = gen.pivot_inv(v);
+      W[e] = v;
+    }
+    const uint32_t oV = (uint32_t)(P.nC + P.nL);
+    for (int j = 0, r = tid; r < P.n; j++, r += T) {
+      SpiceyCx acc{0.0, 0.0};
+      if (j >= 32 || ((rr.rowsrc >> j) & 1u)) {
+        for (uint32_t k = P.rhs_ptr[r]; k < P.rhs_ptr[r + 1]; k++) {
+          const uint32_t ix = P.rhs_idx[k], u = SPICEY_IDX(ix);
+          if (u < oV || u >= oV + (uint32_t)P.nV) continue;
+          const double *phs = R.vph + (inst * P.nV + (u - oV)) * 2;
+          const SpiceyCx v{phs[0], phs[1]};
+          acc = (ix & SPICEY_NEG) ? cx_sub(acc, v) : cx_add(acc, v);
+        }
+      }
+      W[P.nLU + r] = acc;
+    }
+  }
+
+  // one 16-byte record in complex arithmetic (formats: program.h "compact 16-bit task records")
+  template <bool ktask>
+  SPICEY_HD void exec(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const AcPhases<Exec> &gen) const {
+    const uint32_t meta = w0 >> 16;
+    if (!(meta & (SPICEY_R16_VALID << 8))) return;
+    const uint32_t tgt = w0 & 0xffffu, cnt = meta & 0xffu;
+    SpiceyCx acc = W[tgt];
+    if (ktask) {
+      const uint32_t d = w1 & 0xffffu;
+      if (cnt <= 2) {
+        if (cnt >= 1) acc = cx_sub(acc, cx_mul(W[w1 >> 16], W[w2 & 0xffffu]));
+        if (cnt == 2) acc = cx_sub(acc, cx_mul(W[w2 >> 16], W[w3 & 0xffffu]));
+      } else {
+        const uint16_t *o = P.ovf16 + w3;
+        for (uint32_t j = 0; j < cnt; j++) acc = cx_sub(acc, cx_mul(W[o[2 * j]], W[o[2 * j + 1]]));
+      }
+      W[tgt] = cx_mul(acc, W[d]);
+    } else {
+      if (cnt <= 2) {
+        if (cnt >= 1) acc = cx_sub(acc, cx_mul(cx_mul(W[w1 & 0xffffu], W[w1 >> 16]), W[w2 & 0xffffu]));
+        if (cnt == 2) acc = cx_sub(acc, cx_mul(cx_mul(W[w2 >> 16], W[w3 & 0xffffu]), W[w3 >> 16]));
+      } else {
+        const uint16_t *o = P.ovf16 + w3;
+        for (uint32_t j = 0; j < cnt; j++) acc = cx_sub(acc, cx_mul(cx_mul(W[o[3 * j]], W[o[3 * j + 1]]), W[o[3 * j + 2]]));
+      }
+      if (meta & (SPICEY_R16_RECIP << 8)) acc = gen.pivot_inv(acc);
+      W[tgt] = acc;
+    }
+  }
+  template <bool ktask>
+  SPICEY_HD void phase_tasks(int tid, const Regs &rr, int p, const AcPhases<Exec> &gen) const {
+    SPICEY_UNROLL
+    for (int s = 0; s < RMAX; s++)
+      if (SPICEY_UNIFORM((int)((rr.phv[s >> 2] >> ((s & 3) * 8)) & 0xffu)) == p) {
+        exec<ktask>(rr.w0[s], rr.w1[s], rr.w2[s], rr.w3[s], gen);
+        SPICEY_SCHED_FENCE;  // one task at a time: interleaving the slots' operand fetches only costs registers
+      }
+    const uint32_t sc = Q.st_cnt[p];
+    if (sc) {
+      const uint32_t *base = P.rec16 + (size_t)Q.st_first[p] * 4;
+      SPICEY_NOUNROLL
+      for (uint32_t j = (uint32_t)tid; j < sc; j += (uint32_t)T) {
+        const uint32_t *r = base + (size_t)j * 4;
+        exec<ktask>(r[0], r[1], r[2], r[3], gen);
+      }
+    }
+  }
+};
+
+// All frequencies fi = f0, f0 + fstride, ... of instance `inst` by one workgroup.  Control flow is workgroup-uniform.
+template <int RMAX, int NSE, class Exec>
+SPICEY_HD void spicey_ac_sweep_resident(Exec &ex, const SpiceyProg &P, const SpiceyResident &Q, const SpiceyAcRun &R, SpiceyCx *W, int32_t *flags,
+                                        size_t inst, int64_t f0, int64_t fstride) {
+  typedef AcResRegs<RMAX, NSE> Regs;
+  const double two_pi = 2 * 3.141592653589793;
+  const int T = ex.threads();
+  AcResident<Exec, RMAX, NSE> rs{P, Q, R, W, flags, T, inst};
+  {
+    AcPhases<Exec> gen{P, R, W, flags, T, inst, 0.0};
+    ex.phase(SPICEY_PH_PRO, [&](int tid) {
+      if (tid == 0) flags[0] = 0;
+      rs.load(tid, ex.template regs<Regs>(tid), gen);
+    });
+  }
+  const int nL = P.nLevels;
+  for (int64_t fi = f0; fi < R.n_freq; fi += fstride) {
+    AcPhases<Exec> gen{P, R, W, flags, T, inst, two_pi * R.freqs[fi]};
+    ex.phase(SPICEY_PH_B, [&](int tid) { rs.stamp(tid, ex.template regs<Regs>(tid), gen); });
+    for (int p = 0; p < 2 * nL; p++) {
+      if (P.ph_cnt[p] == 0) continue;
+      if (p < nL) ex.phase(SPICEY_PH_U0, [&](int tid) { rs.template phase_tasks<false>(tid, ex.template regs<Regs>(tid), p, gen); });
+      else ex.phase(SPICEY_PH_K0, [&](int tid) { rs.template phase_tasks<true>(tid, ex.template regs<Regs>(tid), p, gen); });
+    }
+    const int code = flags[0];
+    ex.phase(SPICEY_PH_Z, [&](int tid) {
+      if (code == 0) gen.z_record(tid, fi);
+      if (tid == 0) {
+        R.status[inst * (size_t)R.n_freq + (size_t)fi] = code;
+        flags[0] = 0;  // for the next frequency (nothing else touches the flag in this phase)
+      }
+    });
+  }
+}

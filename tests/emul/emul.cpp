@@ -261,8 +261,23 @@ extern "C" int32_t spicey_emul_ac(const SpiceyDesc *d, int32_t T, int64_t n_freq
   R.n_freq = n_freq; R.n_inst = d->n_inst;
   std::vector<SpiceyCx> W((size_t)P.nW + 1);
   int32_t flags[2] = {0, 0};
+  if (reverse & 2) {
+    // resident sweep (bit 1): one emulated workgroup per (instance, residue class of 3 frequencies); small register
+    // capacities (8 record slots, 2 entries per thread) so that the streamed / beyond-capacity paths run too
+    if (!P.has16) return SPICEY_ERR_BAD_DESC;
+    HostResident hr;
+    spicey_build_resident(hp, T, 8, hr, 0);
+    SpiceyResident Q = hr.bind(hr.blob.data());
+    for (int in = 0; in < d->n_inst; in++)
+      for (int64_t f0 = 0; f0 < 3 && f0 < n_freq; f0++) {
+        SeqExec ex{T, (reverse & 1) != 0};
+        std::vector<AcResRegs<8, 2>> regs(T);
+        ex.rr = &regs;
+        spicey_ac_sweep_resident<8, 2>(ex, P, Q, R, W.data(), flags, (size_t)in, f0, 3);
+      }
+  } else
   for (size_t s = 0; s < slots; s++) {
-    SeqExec ex{T, reverse != 0};
+    SeqExec ex{T, (reverse & 1) != 0};
     spicey_ac_solve(ex, P, R, W.data(), flags, (int64_t)s);
   }
   for (size_t s = 0; s < slots; s++)

@@ -99,3 +99,33 @@ def test_ac_large_mesh_global_workspace(oracle_backend):
     assert got["status"] == 0 and be.info["lds_bytes"] == 0
     ref = oracle_backend.run_ac(flat, freqs, vph)
     assert cratio(got["out_v"], ref["out_v"]).max() <= 1.0 and cratio(got["out_i"], ref["out_i"]).max() <= 1.0
+
+
+def test_ac_resident_sweep_on_gpu(oracle_backend):
+    """Batches that outnumber the CUs take the resident sweep (persistent workgroup per instance and frequency class, task
+    records and frequency-independent stamp parts in registers): same parity bar as the per-solve kernel, to which it must
+    agree within rounding; the info block says which one ran."""
+    from spicey_amd import synth
+    from spicey_amd.lib import AcHandle
+    flat, _, _, _ = synth.chain_batch("rc_ladder", 300, range(1, 9), tran=".tran 1e-6 3e-5")  # 8 instances
+    freqs = np.array(sac.logspace(1e3, 1e8, 16))[:80]                                          # x 80 frequencies = 640 solves
+    vph = np.array([1.0 + 0.25j])
+    ref = oracle_backend.run_ac(flat, freqs, vph)
+    h = AcHandle(flat)
+    got = h.run(freqs, vph)
+    assert got["status"] == 0 and h.info()["interpreter"] == 2 and h.info()["resident_tasks"] > 0
+    tol = lambda a, b: (np.abs(a - b) / (1e-9 * np.abs(b) + 1e-12)).max()
+    assert tol(got["out_v"], ref["out_v"]) <= 1.0 and tol(got["out_i"], ref["out_i"]) <= 1.0
+    h2 = AcHandle(flat, no_resident=True)
+    one = h2.run(freqs, vph)
+    assert one["status"] == 0 and h2.info()["interpreter"] == 1
+    assert tol(got["out_v"], one["out_v"]) <= 1.0 and tol(got["out_i"], one["out_i"]) <= 1.0
+    # RLC (entries with inductor stamps keep the reference's per-stamp sequence) and an error inside a batch
+    g = load_golden("ac_rlc")
+    ckt = parseNetlist(golden_netlist(g))
+    f3 = abi.flatten(ckt).replicate(6)
+    fr = np.array(sac.logspace(10.0, 1e7, 20))[:110]
+    r3 = AcHandle(f3)
+    g3 = r3.run(fr, sac.source_phasors(ckt))
+    o3 = oracle_backend.run_ac(f3, fr, sac.source_phasors(ckt))
+    assert g3["status"] == 0 and r3.info()["interpreter"] == 2 and tol(g3["out_v"], o3["out_v"]) <= 1.0 and tol(g3["out_i"], o3["out_i"]) <= 1.0

@@ -305,6 +305,38 @@ def test_ac_program_matches_reference_goldens(name, oracle_backend):
         assert cratio(first["out_v"][0, :, i - 1], cplx(g["V"][names[i]])).max() <= 1.0
 
 
+@pytest.mark.parametrize("name", AC_GOLDENS + ["ac_rc1000"])
+def test_ac_resident_sweep_matches_reference_goldens(name, oracle_backend):
+    """Resident sweep (one persistent workgroup per instance and residue class of frequencies; task records and the
+    frequency-independent stamp parts in registers; row-oriented backward records): same parity bar, both thread orders,
+    small register capacities so that streamed phases and beyond-capacity entries run too."""
+    g, ckt, flat, freqs, vph = _ac_inputs(name)
+    ref = oracle_backend.run_ac(flat, freqs, vph)
+    first = None
+    for T, rev in ((64, False), (256, True)):
+        got = EmulBackend(1, T, rev, ac_resident=True).run_ac(flat, freqs, vph)
+        assert got["status"] == 0
+        assert cratio(got["out_v"], ref["out_v"]).max() <= 1.0 and cratio(got["out_i"], ref["out_i"]).max() <= 1.0
+        if first is None:
+            first = got
+        assert np.array_equal(got["out_v"], first["out_v"]) and np.array_equal(got["out_i"], first["out_i"])
+
+
+def test_ac_resident_sweep_errors_and_batches(oracle_backend):
+    from spicey_amd import ac as sac
+    gf = load_golden("ac_err_float")
+    with pytest.raises(sac.SingularComplexMatrixError):
+        sac.simulateAC(parseNetlist(golden_netlist(gf)), backend=EmulBackend(1, 64, ac_resident=True))
+    tiny = parseNetlist("* tiny\nV1 1 0 ac 1\nR1 1 0 1k\nC1 1 2 1e-12\nC2 2 0 1e-12\n.ac lin 2 1 2\n.end")
+    with pytest.raises(ZeroDivisionError, match="Complex divide by ~0"):
+        sac.simulateAC(tiny, backend=EmulBackend(1, 64, ac_resident=True))
+    flat, _, _, _ = synth.chain_batch("rc_ladder", 40, range(1, 5), tran=".tran 1e-6 3e-5")
+    freqs = np.array([1e3, 3e4, 1e6, 2.5e7, 7e7])
+    ref = oracle_backend.run_ac(flat, freqs, np.array([1.0 + 0.5j]))
+    got = EmulBackend(1, 64, True, ac_resident=True).run_ac(flat, freqs, np.array([1.0 + 0.5j]))
+    assert got["status"] == 0 and cratio(got["out_v"], ref["out_v"]).max() <= 1.0 and cratio(got["out_i"], ref["out_i"]).max() <= 1.0
+
+
 def test_ac_program_public_api_and_errors(oracle_backend):
     from spicey_amd import ac as sac
     g, ckt, flat, freqs, vph = _ac_inputs("ac_readme")

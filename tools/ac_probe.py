@@ -13,13 +13,13 @@ ap.add_argument("--inst", type=int, nargs="+", default=[1, 64])
 ap.add_argument("--freqs", type=int, default=201)
 ap.add_argument("--threads", type=int, nargs="+", default=[0])
 ap.add_argument("--check", type=int, default=1)
+ap.add_argument("--no-resident", action="store_true", help="one workgroup per (instance, frequency) even for large batches")
 args = ap.parse_args()
 freqs = np.array(sac.logspace(1e3, 1e8, (args.freqs - 1) / 5.0))[: args.freqs]
 for ni in args.inst:
     flat, _, _, _ = synth.chain_batch("rc_ladder", args.n, range(1, ni + 1), tran=".tran 1e-6 3e-5")
     for T in args.threads:
-        h = AcHandle(flat, threads=T)
-        info = h.info()
+        h = AcHandle(flat, threads=T, no_resident=args.no_resident)
         best = None
         for rep in range(3):
             t0 = time.time()
@@ -27,7 +27,9 @@ for ni in args.inst:
             wall = time.time() - t0
             assert r["status"] == 0, r["detail"]
             best = r["kernel_ms"] if best is None else min(best, r["kernel_ms"])
-        rec = dict(n=args.n, inst=ni, freqs=len(freqs), T=info["threads"], lds=info["lds_bytes"], nnz_lu=info["nnz_lu"], levels=info["n_levels"],
+        info = h.info()
+        rec = dict(n=args.n, inst=ni, freqs=len(freqs), T=info["threads"], mode="resident sweep" if info["interpreter"] == 2 else "one workgroup per solve",
+                   resident_tasks=info["resident_tasks"], streamed_tasks=info["streamed_tasks"], lds=info["lds_bytes"], nnz_lu=info["nnz_lu"], levels=info["n_levels"],
                    kernel_ms=best, solves=ni * len(freqs), solves_per_s=ni * len(freqs) / (best * 1e-3), wall_ms=wall * 1e3)
         if args.check and ni * len(freqs) * args.n <= 3e6 and args.n <= 300:
             from oracle.pyoracle import OracleBackend
