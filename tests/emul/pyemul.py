@@ -16,8 +16,10 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        subprocess.run(["make", "-s", "-C", _HERE], check=True)
-        L = C.CDLL(os.path.join(_HERE, "_build", "libspicey_emul.so"))
+        # SPICEY_EMUL_ASAN=1 (with LD_PRELOAD=$(gcc -print-file-name=libasan.so)): the address / UB sanitizer build
+        asan = os.environ.get("SPICEY_EMUL_ASAN") == "1"
+        subprocess.run(["make", "-s", "-C", _HERE] + (["asan"] if asan else []), check=True, stderr=subprocess.DEVNULL)
+        L = C.CDLL(os.path.join(_HERE, "_build", "libspicey_emul_asan.so" if asan else "libspicey_emul.so"))
         f64p, i32p, i64p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
         L.spicey_emul_run.restype = C.c_int32
         L.spicey_emul_run.argtypes = [C.POINTER(abi.SpiceyDesc), C.c_int32, C.c_int32, C.c_int64, C.c_double, f64p, f64p, f64p,
