@@ -93,6 +93,7 @@ typedef struct SpiceyOptions {
                             bit 2 = plain CSR numbering of the L+U entries (no LDS-bank-aware slot-major numbering);
                             bit 3 = dense fronts above 64 rows take the staged (global-memory) path even if they fit LDS;
                             bit 4 = AC: never use the resident sweep (one workgroup per (instance, frequency) always);
+                            bit 5 = no tridiagonal top (interpreter 2 keeps its task lists for the top levels of a chain);
                             bits 8.. = extra empty phases per solve */
   int32_t wgs_per_inst;  /* global-workspace path: workgroups (CUs) cooperating on one instance; 0 auto, 1 = none */
   int32_t front_cut;     /* dense fronts (large instances): pivots of elimination-tree level >= front_cut are factored as
@@ -125,6 +126,8 @@ typedef struct SpiceyInfo {
   int32_t front_cut;        /* first elimination-tree level handled by fronts (0 = none) */
   int32_t max_front;        /* rows of the largest front (padded to 16) */
   int64_t front_ws_bytes;   /* front workspace per instance */
+  int32_t pcr_rows;         /* interpreter 2: rows of the tridiagonal top solved by one wave with parallel cyclic reduction (0 = none) */
+  int32_t pcr_level;        /* first elimination-tree level of that top */
 } SpiceyInfo;
 
 typedef struct SpiceyHandle SpiceyHandle;

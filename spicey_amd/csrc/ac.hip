@@ -133,7 +133,7 @@ extern "C" int32_t spicey_ac_create(const SpiceyDesc *desc, const SpiceyOptions 
   d.nS = 0;
   d.nD = 0;
   std::string err;
-  int32_t rc = spicey_build_program(&d, h->hp, err);
+  int32_t rc = spicey_build_program(&d, h->hp, err, true, 0, false);  // (task records for every level: the real-valued cyclic reduction of a tridiagonal top is the transient kernel's)
   if (rc != SPICEY_OK) {
     g_ac_err = err;
     delete h;

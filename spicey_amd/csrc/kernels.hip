@@ -310,6 +310,8 @@ struct GpuExecV2 {
   // tail: wave 0 runs `nlev` dependent levels back to back.  LDS operations of one wave execute in order, so a
   // level's ds_writes are seen by the next level's ds_reads without any workgroup barrier; the fences only stop
   // the compiler from moving or caching LDS accesses across levels.
+  template <class F>
+  __device__ __forceinline__ void wave_lockstep(int nlanes, int nsteps, F f) { gpu_wave_lockstep(nlanes, nsteps, f); }
   template <class L, class F>
   __device__ __forceinline__ void tail_phase(int tag, int nlev, L load, F f) {
     long long t0 = 0;
@@ -430,6 +432,7 @@ size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds, int tail_n) {
   if (!lds) return 64 + spicey_front_lds_bytes(P);
   size_t b = ((size_t)P.nW + P.nU + P.nGdyn) * K * sizeof(double) + ((size_t)P.nS * K + 4) * sizeof(int32_t);
   b = ((b + 15) & ~size_t(15)) + SPICEY_PH_SLOTS * sizeof(unsigned long long);  // + profiling accumulators
+  if (P.pcr_n > 0 && tail_n < 5) tail_n = 5;                                         // tridiagonal top: two 2 KB row buffers + its index table
   b = ((b + 15) & ~size_t(15)) + (size_t)tail_n * 64 * 16;                          // + tail task records
   b += spicey_front_lds_bytes(P);                                                    // + dense-front scratch (32-bit interpreter only)
   return (b + 15) & ~size_t(15);

@@ -124,6 +124,13 @@ struct SpiceyProg {
   const uint32_t *ph_cnt;    // [2 nLevels]
   int32_t nRec16;
   int32_t has16;             // 0 when nW >= 65536 (global-workspace path only)
+  // Tridiagonal top (16-bit records only): when the <= 64 pivots of level >= pcr_level see each other, after the levels
+  // below are eliminated, only along a PATH (ladders, chains, lines), their Schur complement is tridiagonal and one wave
+  // solves it by parallel cyclic reduction (log2 steps, no factor / backward levels above pcr_level: their phases hold no
+  // records).  pcr_tab[i] = W indices {sub-diagonal (t_i, t_i-1), diagonal, super-diagonal (t_i, t_i+1), right-hand side}
+  // of row i in path order, 0xFFFF = none.
+  int32_t pcr_n, pcr_level;
+  const uint16_t *pcr_tab;   // [pcr_n][4]
 
   // --- dense fronts (nFronts > 0): pivots of elimination-tree level >= front_cut are factored front by front
   //     (multifrontal: assemble from W + children's contribution blocks, blocked dense LU in LDS, trailing update),

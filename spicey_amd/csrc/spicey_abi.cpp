@@ -138,7 +138,9 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   int front_cut = h->opt.front_cut > 0 ? h->opt.front_cut : (h->opt.front_cut == 0 ? -1 : 0);
   if (h->opt.inst_per_wg > 1 || h->opt.interpreter == 2) front_cut = 0;
   if (front_cut < 0 && desc && desc->n_inst >= 512) front_cut = 0;  // big batches fill the chip with interleaved instances instead
-  int32_t rc = spicey_build_program(desc, h->hp, err, !((h->opt.debug >> 2) & 1), front_cut);  // diagnostics: bit 2 = plain CSR numbering
+  // tridiagonal top by cyclic reduction (16-bit records, one instance per workgroup); diagnostics: bit 5 = never
+  const bool pcr_top = !((h->opt.debug >> 5) & 1) && h->opt.inst_per_wg <= 1;
+  int32_t rc = spicey_build_program(desc, h->hp, err, !((h->opt.debug >> 2) & 1), front_cut, pcr_top);  // diagnostics: bit 2 = plain CSR numbering
   if (rc != SPICEY_OK) {
     g_err = err;
     delete h;
@@ -348,6 +350,8 @@ extern "C" int32_t spicey_get_info(SpiceyHandle *h, SpiceyInfo *info) {
   info->front_cut = h->hp.hdr.front_cut;
   info->max_front = h->hp.hdr.max_front_mp;
   info->front_ws_bytes = h->hp.hdr.front_ws * (int64_t)sizeof(double);
+  info->pcr_rows = (h->interp == 2 && h->K == 1) ? h->hp.hdr.pcr_n : 0;
+  info->pcr_level = info->pcr_rows ? h->hp.hdr.pcr_level : 0;
   return SPICEY_OK;
 }
 

@@ -329,7 +329,7 @@ int64_t spicey_algorithmic_bytes(const SpiceyDesc *d, int32_t nnzA, int32_t nnzL
          16 * ((int64_t)d->nC + d->nL + d->nD) + 8 * ((int64_t)d->n_nodes + etot);
 }
 
-static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool slot_major, int front_cut);
+static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool slot_major, int front_cut, bool pcr_top);
 
 
 // LDS cycles the operand reads of the compact records cost per solve (every half-wave group and operand role: the
@@ -369,13 +369,13 @@ void spicey_bank_cost(const HostProgram &hp, int64_t *cycles, int64_t *ideal) {
 // order.  For programs that run from LDS (16-bit records) both are compiled and the one whose operand reads cost fewer
 // LDS cycles is kept (chains: 2.65 -> 1.88 conflict factor; small meshes are sometimes better off in CSR order).
 // Circuits on the global-workspace path keep the CSR order: LDS banks do not matter there.
-int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware, int front_cut) {
+int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware, int front_cut, bool pcr_top) {
   hp = HostProgram();
-  int32_t rc = build_program_impl(d, hp, err, false, front_cut);
+  int32_t rc = build_program_impl(d, hp, err, false, front_cut, pcr_top);
   if (rc != SPICEY_OK || hp.structurally_singular || !hp.hdr.has16 || !bank_aware) return rc;
   HostProgram alt;
   std::string err2;
-  if (build_program_impl(d, alt, err2, true, 0) == SPICEY_OK && alt.hdr.has16) {
+  if (build_program_impl(d, alt, err2, true, 0, pcr_top) == SPICEY_OK && alt.hdr.has16) {
     int64_t c0, i0, c1, i1;
     spicey_bank_cost(hp, &c0, &i0);
     spicey_bank_cost(alt, &c1, &i1);
@@ -384,7 +384,7 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
   return rc;
 }
 
-static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, const bool slot_major, int front_cut) {
+static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, const bool slot_major, int front_cut, const bool pcr_top) {
   if (!d) { err = "null descriptor"; return SPICEY_ERR_BAD_DESC; }
   if (d->abi_version != SPICEY_ABI_VERSION) { err = "abi_version mismatch"; return SPICEY_ERR_BAD_DESC; }
   const int nN = d->n_nodes, nR = d->nR, nC = d->nC, nL = d->nL, nV = d->nV, nS = d->nS, nD = d->nD;
@@ -961,6 +961,72 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   // ---- 5c'. compact 16-bit records of the same tasks, phases in execution order -------------------
   hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear(); hp.ph_rhs.clear();
   hp.hdr.has16 = ((nLU + n) < 65535 && Lc == 0) ? 1 : 0;  // 0xFFFF = ground in the packed terminal words; fronts run under the 32-bit interpreter
+  // Tridiagonal top: T = the pivots of the highest levels, at most 64 of them (one row per lane of a wave).  Two of them are coupled, once everything
+  // below is eliminated, iff the original matrix couples them or some lower pivot has both in its row structure.  If that
+  // coupling graph is a path, the Schur complement on T is tridiagonal in path order and the records stop below T.
+  hp.pcr_tab.clear();
+  hp.hdr.pcr_n = 0; hp.hdr.pcr_level = 0;
+  std::vector<char> in_top(n, 0);
+  int pcrL = 0;
+  if (pcr_top && hp.hdr.has16 && nLevels >= 4 && !hp.structurally_singular) {
+    int cnt = 0, L0 = nLevels;
+    while (L0 > 1 && cnt + (int)by_level[L0 - 1].size() <= 64) { L0--; cnt += (int)by_level[L0].size(); }  // one row per lane of the solving wave
+    if (cnt >= 15 && L0 >= 1 && L0 < nLevels) {
+      std::vector<int> T;
+      for (int k = 0; k < n; k++)
+        if (hp.level[k] >= L0) { in_top[k] = 1; T.push_back(k); }
+      std::vector<std::vector<int>> H(n);
+      auto link = [&](int a, int b) { if (a != b) { H[a].push_back(b); H[b].push_back(a); } };
+      for (int c = 0; c < n; c++)  // original couplings
+        for (int c2 : g[c]) {
+          const int a = hp.cpos[c], b = hp.cpos[c2];
+          if (a < b && in_top[a] && in_top[b]) link(a, b);
+        }
+      for (int k = 0; k < n; k++) {  // fill through the pivots below
+        if (in_top[k]) continue;
+        std::vector<int> tk;
+        for (int a : upper[k]) if (in_top[a]) tk.push_back(a);
+        for (size_t i = 0; i < tk.size(); i++)
+          for (size_t j = i + 1; j < tk.size(); j++) link(tk[i], tk[j]);
+      }
+      bool path = true;
+      size_t edges = 0;
+      int end0 = -1;
+      for (int t : T) {
+        sort_unique(H[t]);
+        edges += H[t].size();
+        if (H[t].size() > 2) path = false;
+        if (H[t].size() <= 1 && (end0 < 0 || t < end0)) end0 = t;
+      }
+      if (edges != 2 * (T.size() - 1) || end0 < 0) path = false;
+      std::vector<int> ord;
+      if (path) {
+        int prev = -1, cur = end0;
+        while (cur >= 0) {
+          ord.push_back(cur);
+          int nxt = -1;
+          for (int w : H[cur]) if (w != prev) nxt = w;
+          prev = cur; cur = nxt;
+          if (ord.size() > T.size()) { path = false; break; }
+        }
+        if (ord.size() != T.size()) path = false;  // (a cycle-free walk that covers T: connected)
+      }
+      if (path) {
+        for (size_t i = 0; i < ord.size(); i++) {
+          const int t = ord[i];
+          const int a = i > 0 ? E.find(t, ord[i - 1]) : -2, c2 = i + 1 < ord.size() ? E.find(t, ord[i + 1]) : -2;
+          if (a == -1 || c2 == -1) { path = false; break; }
+          hp.pcr_tab.push_back(a < 0 ? (uint16_t)0xFFFF : (uint16_t)a);
+          hp.pcr_tab.push_back((uint16_t)diag[t]);
+          hp.pcr_tab.push_back(c2 < 0 ? (uint16_t)0xFFFF : (uint16_t)c2);
+          hp.pcr_tab.push_back((uint16_t)(nLU + t));
+        }
+      }
+      if (path) { hp.hdr.pcr_n = (int32_t)ord.size(); hp.hdr.pcr_level = L0; pcrL = L0; }
+      else { hp.pcr_tab.clear(); std::fill(in_top.begin(), in_top.end(), 0); }
+    }
+  }
+  if (pcrL == 0) std::fill(in_top.begin(), in_top.end(), 0);
   if (hp.hdr.has16) {
     auto emit_u = [&](uint32_t tgt, bool recip, const std::vector<uint32_t> &tr) {  // tr = (l,d,u)*
       const uint32_t cnt = (uint32_t)(tr.size() / 3);
@@ -991,6 +1057,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     bool too_long = false;
     for (int l = 0; l < nLevels; l++) {  // factor phases: re-derive the grouped tasks of level l
       hp.ph_first.push_back((uint32_t)(hp.rec16.size() / 4));
+      if (pcrL > 0 && l >= pcrL) { hp.ph_rhs.push_back(0u); hp.ph_cnt.push_back(0u); continue; }  // solved by cyclic reduction
       struct Prod { uint32_t tgt, l, d, u; int32_t si, sj, k; };  // si / sj: slots of the L / U operand in upper[k] (sj = -1: rhs)
       std::vector<Prod> prods;
       for (int k : by_level[l]) {
@@ -1018,7 +1085,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
         bool recip = false;
         if ((int)t < nLU) {
           const int r = E.row_of_id[t];
-          recip = E.col_of_id[t] == r && hp.level[r] == l + 1;
+          recip = E.col_of_id[t] == r && hp.level[r] == l + 1 && !in_top[r];  // (the cyclic reduction wants the diagonal itself)
         }
         if (tr.size() / 3 > 255) too_long = true;
         uts.push_back({t, recip, std::move(tr), prods[i].si, prods[i].sj, prods[i].k});
@@ -1045,6 +1112,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     }
     for (int l = nLevels - 1; l >= 0; l--) {  // backward phases, top level first
       hp.ph_first.push_back((uint32_t)(hp.rec16.size() / 4));
+      if (pcrL > 0 && l >= pcrL) { hp.ph_cnt.push_back(0u); continue; }
       std::vector<int> ks = by_level[l];
       std::stable_sort(ks.begin(), ks.end(), [&](int x, int y) { return upper[x].size() > upper[y].size(); });
       for (int k : ks) {
@@ -1057,6 +1125,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     }
     if (too_long || hp.ovf16.size() >= (size_t)1 << 31) {  // count field is 8 bits: such circuits use the 32-bit path
       hp.hdr.has16 = 0;
+      hp.hdr.pcr_n = 0; hp.hdr.pcr_level = 0; hp.pcr_tab.clear();
       hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear(); hp.ph_rhs.clear();
     }
   }
@@ -1176,6 +1245,7 @@ void HostProgram::pack() {
   add_section(blob, offsets, fr_bnd);    // 50
   add_section(blob, offsets, fr_child);  // 51
   add_section(blob, offsets, fr_rel);    // 52
+  add_section(blob, offsets, pcr_tab);   // 53
 }
 
 SpiceyProg HostProgram::bind(const void *base) const {
@@ -1198,6 +1268,7 @@ SpiceyProg HostProgram::bind(const void *base) const {
   p.R_ab = u32(44); p.C_ab = u32(45); p.L_ab = u32(46); p.D_ab = u32(47);
   p.fr = (const SpiceyFront *)(b + offsets[48]);
   p.fr_asm = u32(49); p.fr_bnd = u32(50); p.fr_child = u32(51); p.fr_rel = u32(52);
+  p.pcr_tab = (const uint16_t *)(b + offsets[53]);
   return p;
 }
 
@@ -1214,7 +1285,7 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
   out.st_first.assign(std::max(nPh, 1), 0u);
   out.st_cnt.assign(std::max(nPh, 1), 0u);
   out.st_rhs.assign(std::max(nPh, 1), 0u);
-  if (hp.hdr.has16 && nPh <= 254 && max_tail > 1) {
+  if (hp.hdr.has16 && nPh <= 254 && max_tail > 1 && hp.hdr.pcr_n == 0) {  // (a tridiagonal top replaces the tail: its phases hold no records)
     // tail: longest run of <= 64-task phases around the factor -> backward turn (phase nLevels-1 | nLevels)
     const int nL = hp.hdr.nLevels;
     int a = nL, b = nL;  // [a, b)

@@ -30,6 +30,7 @@ struct HostProgram {
   std::vector<uint32_t> rec16, ph_first, ph_cnt;  // compact records (has16)
   std::vector<uint32_t> ph_rhs;  // per factor phase: its leading right-hand-side tasks (host only)
   std::vector<uint16_t> ovf16;
+  std::vector<uint16_t> pcr_tab;  // tridiagonal top in path order (hdr.pcr_n rows of 4 W indices), see program.h
   std::vector<uint32_t> ent_dd, dynx_ent, dynx_ptr, dynx_idx, row_desc, rowx, R_ab, C_ab, L_ab, D_ab;
   std::vector<int32_t> R_a, R_b, C_a, C_b, L_a, L_b, S_a, S_b, S_cp, S_cn, D_a, D_b, V_x, out_x;
   // dense fronts above the cut (empty when hdr.nFronts == 0)
@@ -50,7 +51,8 @@ struct HostProgram {
 // run reports SPICEY_ERR_SINGULAR, like the reference throws at the first solve.
 // front_cut: elimination-tree level from which pivots are factored as dense fronts (fronts_exec.h); 0 = no fronts,
 // -1 = automatic (large nonlinear circuits only).
-int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware = true, int front_cut = 0);
+// pcr_top: let the 16-bit records stop below a tridiagonal top that one wave solves by parallel cyclic reduction.
+int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware = true, int front_cut = 0, bool pcr_top = true);
 
 // Front schedule for G cooperating workgroups (proportional mapping of the front tree: a subtree's workgroup range is
 // split among its children by work; a front runs on the first workgroup of its range once its children are done).

@@ -1037,6 +1037,49 @@ struct TranPhases2 {
   }
 };
 
+// ---- tridiagonal top by parallel cyclic reduction (program.h: pcr_n, pcr_tab) -------------------------------------------
+// One wave, lane i = row i of the tridiagonal Schur complement (path order), two SoA buffers {a, b, c, d}[64] in LDS used
+// alternately.  Stage 0 gathers the rows from W; stages 1 .. S (stride 1, 2, 4, ...): row i eliminates its couplings to the
+// rows i -+ stride with those rows' equations; after S = ceil(log2 n) stages every row stands alone and stage S + 1 writes
+// x_i = d_i / b_i into the solution slot.  Replaces 2 x (S + 1) LDS-serial levels of the task lists; no U entries are
+// formed for these pivots (nothing below needs them: the backward records of lower rows read x only).
+template <int K>
+SPICEY_HD void spicey_pcr_stage(const WgCtx<K> &c, double *buf, const uint16_t *tab, int n, int S, int lane, int st) {
+  double *rd = buf + (((st - 1) & 1) ? 256 : 0), *wr = buf + ((st & 1) ? 256 : 0);
+  if (st == 0) {  // gather (stage 0 writes buffer 0)
+    double a = 0.0, b = 1.0, cc = 0.0, d = 0.0;
+    if (lane < n) {
+      const uint32_t ia = tab[lane * 4], ib = tab[lane * 4 + 1], ic = tab[lane * 4 + 2], id = tab[lane * 4 + 3];
+      a = ia == 0xFFFFu ? 0.0 : c.W[(size_t)ia * K];
+      b = c.W[(size_t)ib * K];
+      cc = ic == 0xFFFFu ? 0.0 : c.W[(size_t)ic * K];
+      d = c.W[(size_t)id * K];
+    }
+    wr[lane] = a; wr[64 + lane] = b; wr[128 + lane] = cc; wr[192 + lane] = d;
+    return;
+  }
+  if (st <= S) {
+    const int h = 1 << (st - 1), im = lane - h, ip = lane + h;
+    const double a = rd[lane], b = rd[64 + lane], cc = rd[128 + lane], d = rd[192 + lane];
+    const bool hm = im >= 0, hp = ip < 64;
+    const double bm = rd[64 + (hm ? im : lane)], bp = rd[64 + (hp ? ip : lane)];
+    if (lane < n && ((hm && im < n && fabs(bm) < SPICEY_EPS) || (hp && ip < n && fabs(bp) < SPICEY_EPS)) && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
+    const double al = hm ? -a * spicey_rcp(bm) : 0.0, ga = hp ? -cc * spicey_rcp(bp) : 0.0;
+    const double am = hm ? rd[im] : 0.0, cm = hm ? rd[128 + im] : 0.0, dm = hm ? rd[192 + im] : 0.0;
+    const double ap = hp ? rd[ip] : 0.0, cp = hp ? rd[128 + ip] : 0.0, dp = hp ? rd[192 + ip] : 0.0;
+    wr[lane] = al * am;
+    wr[64 + lane] = fma(ga, ap, fma(al, cm, b));
+    wr[128 + lane] = ga * cp;
+    wr[192 + lane] = fma(ga, dp, fma(al, dm, d));
+    return;
+  }
+  if (lane < n) {  // st == S + 1: the rows are decoupled
+    const double b = rd[64 + lane];
+    if (fabs(b) < SPICEY_EPS && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
+    c.W[(size_t)tab[lane * 4 + 3] * K] = rd[192 + lane] * spicey_rcp(b);
+  }
+}
+
 // The three argument structs hold ~110 pointers: kept in SGPRs across the time loop they overflow the 102 scalar registers
 // of a wave and the compiler parks them in VGPR lanes (round 1: 274 spilled SGPRs, 1 209 v_readlane in the kernel — 13 % of
 // its instructions).  Every phase therefore takes the structs through `ex.fresh()`: on the GPU they live in global memory and
@@ -1060,6 +1103,10 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
     if (tid == 0) { c.flags[0] = 0; c.flags[1] = 0; c.flags[2] = -1; }
     ph.p0_gstat(tid);
     p2.load_resident(tid, Qf, ex.template regs<Regs>(tid));
+    if (K == 1 && Pf.pcr_n > 0) {  // tridiagonal top: its index table sits behind the two 2 KB row buffers
+      uint16_t *tab = (uint16_t *)(c.tail + 1024);
+      for (int i = tid; i < Pf.pcr_n * 4; i += T) tab[i] = Pf.pcr_tab[i];
+    }
     for (int i = tid; i < Qf.tail_n * 64; i += T) {  // tail records -> LDS (16 bytes each; no task = all zero)
       const int p = Qf.tail_first + (i >> 6), lane = i & 63;
       const bool have = (uint32_t)lane < Pf.ph_cnt[p];
@@ -1086,8 +1133,12 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
     if (SPICEY_UNIFORM((int)Q.st_cnt[p]) != 0) smask |= 1ull << p;
   }
   const int tail_n = Q.tail_n, tail_first = Q.tail_first;
-  const int u_end = tail_n > 0 ? tail_first : nL;
-  const int k_begin = tail_n > 0 ? tail_first + tail_n : nL;
+  const int pcr_n = K == 1 ? P.pcr_n : 0;
+  int pcr_S = 0;
+  while ((1 << pcr_S) < pcr_n) pcr_S++;
+  // with a tridiagonal top the factor phases end at its level and the backward phases resume below it
+  const int u_end = pcr_n > 0 ? P.pcr_level : (tail_n > 0 ? tail_first : nL);
+  const int k_begin = pcr_n > 0 ? 2 * nL - P.pcr_level : (tail_n > 0 ? tail_first + tail_n : nL);
   const bool z_pre = K == 1 && k_begin < 2 * nL;  // Z's parameter fetch rides on the last backward phase
   // No diodes and no switches: the matrix of every step is the matrix of step 0 (dt is fixed within a run), so its
   // factors stay in W and later steps run the right-hand-side column only.  Same operands, same order: the results
@@ -1118,7 +1169,11 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
           spicey_uk_phase<K, RMAX, NSV, NEL, false>(Pf, Qf, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true, linear && step > 0);
         });
       }
-      if (k_begin > u_end) {
+      if (pcr_n > 0) {
+        ex.wave_lockstep(64, pcr_S + 2, [&](int lane, int st) {
+          spicey_pcr_stage<K>(c, (double *)c.tail, (const uint16_t *)(c.tail + 1024), pcr_n, pcr_S, lane, st);
+        });
+      } else if (k_begin > u_end) {
         // the record of level l + 1 is fetched (LDS) while level l executes: one round trip less on the serial chain
         ex.tail_phase(SPICEY_PH_U0 + 31, k_begin - u_end,
                       [&](int tid, int lvl, uint32_t *r) {

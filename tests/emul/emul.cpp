@@ -102,7 +102,7 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
       HostResident hr;
       spicey_build_resident(hp, T, rmax, hr, 24);
       SpiceyResident Q = hr.bind(hr.blob.data());
-      std::vector<uint32_t> tail((size_t)(hr.tail_n + 1) * 64 * 4);
+      std::vector<uint32_t> tail((size_t)(hr.tail_n + 6) * 64 * 4);  // (+ the cyclic-reduction buffers of a tridiagonal top)
       c.tail = tail.data();
       // NSV = 2 resident entries per thread: small on purpose so that tests also cover the streamed remainder
       // NEL = 2 resident elements / rows per thread: with the small T the tests use, the remainder loops run too.
@@ -128,7 +128,8 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
   HostProgram hp;
   std::string err;
   const int front_cut = reverse >> 8;  // bits 8..: elimination-tree level from which pivots are factored as dense fronts
-  int32_t rc = spicey_build_program(d, hp, err, true, front_cut);
+  // bit 4: no tridiagonal top (the 16-bit records then cover every level); interleaved instances (K > 1) never use it
+  int32_t rc = spicey_build_program(d, hp, err, true, front_cut, !(reverse & 16) && K == 1);
   if (rc != SPICEY_OK) return rc;
   SpiceyProg P = hp.bind(hp.blob.data());
   if (info) {
@@ -138,6 +139,8 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
     info->program_bytes = (int64_t)hp.blob.size();
     info->algorithmic_bytes_solve = spicey_algorithmic_bytes(d, hp.nnzA, P.nLU);
     info->n_workgroups = (d->n_inst + K - 1) / K;
+    info->pcr_rows = (rmax >= 0 && K == 1) ? P.pcr_n : 0;
+    info->pcr_level = info->pcr_rows ? P.pcr_level : 0;
   }
   if (hp.structurally_singular) {
     if (err4) { err4[0] = 1; err4[1] = 0; err4[2] = 0; err4[3] = 0; }
@@ -217,10 +220,11 @@ extern "C" int32_t spicey_emul_symbolic(const SpiceyDesc *d, int32_t *cpos, int3
 // Resident-layout introspection for structural tests: phase of every (wave, slot), per-phase counts and tail.
 extern "C" int32_t spicey_emul_resident(const SpiceyDesc *d, int32_t T, int32_t rmax, int32_t max_tail, int32_t *res_phase /*[T/64][rmax]*/,
                                         uint32_t *res_valid /*[rmax][T] 1 if the slot holds a task*/, uint32_t *ph_cnt /*[2L]*/,
-                                        uint32_t *st_cnt /*[2L]*/, int32_t *meta /*[4]: nLevels, tail_first, tail_n, has16*/) {
+                                        uint32_t *st_cnt /*[2L]*/, int32_t *meta /*[6]: nLevels, tail_first, tail_n, has16, pcr_n, pcr_level*/,
+                                        int32_t pcr_top) {
   HostProgram hp;
   std::string err;
-  int32_t rc = spicey_build_program(d, hp, err);
+  int32_t rc = spicey_build_program(d, hp, err, true, 0, pcr_top != 0);
   if (rc != SPICEY_OK) return rc;
   HostResident hr;
   spicey_build_resident(hp, T, rmax, hr, max_tail);
@@ -230,6 +234,7 @@ extern "C" int32_t spicey_emul_resident(const SpiceyDesc *d, int32_t T, int32_t 
     for (int t = 0; t < T; t++) res_valid[(size_t)s * T + t] = (hr.res[((size_t)s * T + t) * 4] >> 16 & (SPICEY_R16_VALID << 8)) ? 1u : 0u;
   for (int p = 0; p < nPh; p++) { ph_cnt[p] = hp.ph_cnt[p]; st_cnt[p] = hr.st_cnt[p]; }
   meta[0] = hp.hdr.nLevels; meta[1] = hr.tail_first; meta[2] = hr.tail_n; meta[3] = hp.hdr.has16;
+  meta[4] = hp.hdr.pcr_n; meta[5] = hp.hdr.pcr_level;
   return SPICEY_OK;
 }
 
@@ -241,7 +246,7 @@ extern "C" int32_t spicey_emul_ac(const SpiceyDesc *d, int32_t T, int64_t n_freq
   dd.nD = 0;
   HostProgram hp;
   std::string err;
-  int32_t rc = spicey_build_program(&dd, hp, err);
+  int32_t rc = spicey_build_program(&dd, hp, err, true, 0, false);
   if (rc != SPICEY_OK) return rc;
   SpiceyProg P = hp.bind(hp.blob.data());
   if (info) {

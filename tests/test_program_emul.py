@@ -174,8 +174,8 @@ def test_resident_layout_invariants(T, rmax, max_tail):
     and the tail is a contiguous run of <= 64-task phases around the factor -> backward turn."""
     from emul.pyemul import resident_layout
     flat = abi.flatten(parseNetlist(synth.diode_chain(1000)))
-    rc, res_phase, res_valid, ph_cnt, st_cnt, meta = resident_layout(flat, T, rmax, max_tail)
-    nL, t0, tn, has16 = (int(x) for x in meta)
+    rc, res_phase, res_valid, ph_cnt, st_cnt, meta = resident_layout(flat, T, rmax, max_tail)  # (task lists for every level: no tridiagonal top)
+    nL, t0, tn, has16 = (int(x) for x in meta[:4])
     assert rc == 0 and has16 == 1 and nL == 11
     nph = 2 * nL
     resident = np.zeros(nph, np.int64)
@@ -202,6 +202,39 @@ def test_resident_layout_invariants(T, rmax, max_tail):
     else:
         assert max_tail < 3 or True
     assert ph_cnt[:nL].sum() + ph_cnt[nL:].sum() == ph_cnt.sum() and ph_cnt[nL:].sum() == 1001  # one backward task per unknown
+
+
+def test_tridiagonal_top_is_found_on_chains_only(oracle_backend):
+    """Where the <= 64 pivots of the top levels couple only along a path (ladders, chains), the 16-bit records stop
+    below them and one wave solves the tridiagonal Schur complement by parallel cyclic reduction: no records, no tail
+    in those phases; meshes / random circuits keep their task lists.  Results: the parity bar, identical in both thread
+    orders, and equal (to rounding) to the run with the task lists for every level; linear circuits keep reusing
+    their factors bit for bit."""
+    from emul.pyemul import resident_layout
+    flat = abi.flatten(parseNetlist(synth.diode_chain(1000)))
+    rc, _, _, ph_cnt, _, meta = resident_layout(flat, 1024, 8, 24, pcr_top=True)
+    nL, t0, tn, has16, pn, pl = (int(x) for x in meta)
+    assert rc == 0 and pn == 64 and pl == 4 and tn == 0
+    assert ph_cnt[pl:nL].sum() == 0 and ph_cnt[nL:2 * nL - pl].sum() == 0 and ph_cnt[nL:].sum() == 1001 - 64
+    meshflat = abi.flatten(parseNetlist(synth.rcd_mesh(12)))
+    assert int(resident_layout(meshflat, 256, 8, 24, pcr_top=True)[5][4]) == 0
+    for kind, n in (("diode_chain", 1000), ("rc_ladder", 300), ("rc_ladder", 40)):
+        flat, dt, steps, src = synth.chain_batch(kind, n, [1, 2, 3], tran=".tran 1e-6 3e-5")
+        ref = oracle_backend.run(flat, steps, dt, src)
+        outs = []
+        for T, rev, rmax in ((256, False, 8), (128, True, 16)):
+            be = EmulBackend(1, T, rev, rmax)
+            got = be.run(flat, steps, dt, src)
+            assert got["status"] == 0 and be.info["pcr_rows"] >= 15
+            assert ratio(got["out_v"], ref["out_v"]).max() <= 1.0 and ratio(got["out_i"], ref["out_i"]).max() <= 1.0
+            outs.append(got)
+        assert np.array_equal(outs[0]["out_v"], outs[1]["out_v"]) and np.array_equal(outs[0]["out_i"], outs[1]["out_i"])
+        lists = EmulBackend(1, 256, False, 8, no_pcr=True)
+        old = lists.run(flat, steps, dt, src)
+        assert lists.info["pcr_rows"] == 0 and ratio(old["out_v"], outs[0]["out_v"]).max() <= 1e-3
+        if kind == "rc_ladder":  # factor reuse of a linear circuit: the cyclic reduction re-reads the step-0 Schur complement
+            again = EmulBackend(1, 256, False, 8, no_reuse=True).run(flat, steps, dt, src)
+            assert np.array_equal(again["out_v"], outs[0]["out_v"]) and np.array_equal(again["out_i"], outs[0]["out_i"])
 
 
 def test_algorithmic_bytes_match_survey():
