@@ -311,7 +311,12 @@ struct GpuExecV2 {
   // level's ds_writes are seen by the next level's ds_reads without any workgroup barrier; the fences only stop
   // the compiler from moving or caching LDS accesses across levels.
   template <class F>
-  __device__ __forceinline__ void wave_lockstep(int nlanes, int nsteps, F f) { gpu_wave_lockstep(nlanes, nsteps, f); }
+  __device__ __forceinline__ void wave_lockstep(int nlanes, int nsteps, F f) {
+    long long t0 = 0;
+    if (prof && threadIdx.x == 0) t0 = clock64();
+    gpu_wave_lockstep(nlanes, nsteps, f);
+    if (prof && threadIdx.x == 0) atomicAdd(&prof[SPICEY_PH_U0 + 31], (unsigned long long)(clock64() - t0));  // (the slot of the tail it replaces)
+  }
   template <class L, class F>
   __device__ __forceinline__ void tail_phase(int tag, int nlev, L load, F f) {
     long long t0 = 0;

@@ -1039,45 +1039,61 @@ struct TranPhases2 {
 
 // ---- tridiagonal top by parallel cyclic reduction (program.h: pcr_n, pcr_tab) -------------------------------------------
 // One wave, lane i = row i of the tridiagonal Schur complement (path order), two SoA buffers {a, b, c, d}[64] in LDS used
-// alternately.  Stage 0 gathers the rows from W; stages 1 .. S (stride 1, 2, 4, ...): row i eliminates its couplings to the
-// rows i -+ stride with those rows' equations; after S = ceil(log2 n) stages every row stands alone and stage S + 1 writes
-// x_i = d_i / b_i into the solution slot.  Replaces 2 x (S + 1) LDS-serial levels of the task lists; no U entries are
-// formed for these pivots (nothing below needs them: the backward records of lower rows read x only).
+// alternately.  Stage 0 gathers the rows from W through the index table; stage st = 1 .. S (stride 1, 2, 4, ...): row i
+// eliminates its couplings to the rows i -+ stride with those rows' equations; after S = ceil(log2 n) stages every row
+// stands alone and the last stage writes x_i = d_i / b_i straight into the solution slot.
+// Replaces 2 x (S + 1) LDS-serial levels of the task lists; no U entries are formed for these pivots (nothing below needs
+// them: the backward records of lower rows read x only).  All loads of a stage are unconditional (clamped addresses, values
+// masked afterwards) so that they are issued together: one LDS round trip per stage.
+template <int K>
+SPICEY_HD void spicey_pcr_row(const WgCtx<K> &c, const uint16_t *tab, int n, int r, double &a, double &b, double &cc, double &d) {
+  const bool on = r >= 0 && r < n;
+  const int rr = on ? r : 0;
+  const uint32_t ia = tab[rr * 4], ib = tab[rr * 4 + 1], ic = tab[rr * 4 + 2], id = tab[rr * 4 + 3];
+  const double va = c.W[(size_t)(ia == 0xFFFFu ? ib : ia) * K], vb = c.W[(size_t)ib * K], vc = c.W[(size_t)(ic == 0xFFFFu ? ib : ic) * K],
+               vd = c.W[(size_t)id * K];
+  a = (on && ia != 0xFFFFu) ? va : 0.0;
+  b = on ? vb : 1.0;  // rows past the end: identity
+  cc = (on && ic != 0xFFFFu) ? vc : 0.0;
+  d = on ? vd : 0.0;
+}
 template <int K>
 SPICEY_HD void spicey_pcr_stage(const WgCtx<K> &c, double *buf, const uint16_t *tab, int n, int S, int lane, int st) {
-  double *rd = buf + (((st - 1) & 1) ? 256 : 0), *wr = buf + ((st & 1) ? 256 : 0);
-  if (st == 0) {  // gather (stage 0 writes buffer 0)
-    double a = 0.0, b = 1.0, cc = 0.0, d = 0.0;
-    if (lane < n) {
-      const uint32_t ia = tab[lane * 4], ib = tab[lane * 4 + 1], ic = tab[lane * 4 + 2], id = tab[lane * 4 + 3];
-      a = ia == 0xFFFFu ? 0.0 : c.W[(size_t)ia * K];
-      b = c.W[(size_t)ib * K];
-      cc = ic == 0xFFFFu ? 0.0 : c.W[(size_t)ic * K];
-      d = c.W[(size_t)id * K];
-    }
+  const double *rd = buf + (((st - 1) & 1) ? 256 : 0);
+  double *wr = buf + ((st & 1) ? 256 : 0);
+  if (st == 0) {  // gather the rows from W (stage 0 writes buffer 0)
+    double a, b, cc, d;
+    spicey_pcr_row<K>(c, tab, n, lane, a, b, cc, d);
     wr[lane] = a; wr[64 + lane] = b; wr[128 + lane] = cc; wr[192 + lane] = d;
     return;
   }
-  if (st <= S) {
-    const int h = 1 << (st - 1), im = lane - h, ip = lane + h;
-    const double a = rd[lane], b = rd[64 + lane], cc = rd[128 + lane], d = rd[192 + lane];
-    const bool hm = im >= 0, hp = ip < 64;
-    const double bm = rd[64 + (hm ? im : lane)], bp = rd[64 + (hp ? ip : lane)];
-    if (lane < n && ((hm && im < n && fabs(bm) < SPICEY_EPS) || (hp && ip < n && fabs(bp) < SPICEY_EPS)) && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
-    const double al = hm ? -a * spicey_rcp(bm) : 0.0, ga = hp ? -cc * spicey_rcp(bp) : 0.0;
-    const double am = hm ? rd[im] : 0.0, cm = hm ? rd[128 + im] : 0.0, dm = hm ? rd[192 + im] : 0.0;
-    const double ap = hp ? rd[ip] : 0.0, cp = hp ? rd[128 + ip] : 0.0, dp = hp ? rd[192 + ip] : 0.0;
-    wr[lane] = al * am;
-    wr[64 + lane] = fma(ga, ap, fma(al, cm, b));
-    wr[128 + lane] = ga * cp;
-    wr[192 + lane] = fma(ga, dp, fma(al, dm, d));
-    return;
+  const int h = 1 << (st - 1), im = lane - h, ip = lane + h;
+  const bool hm = im >= 0, hp = ip < 64;
+  const int jm = hm ? im : lane, jp = hp ? ip : lane;
+  const double a = rd[lane], b = rd[64 + lane], cc = rd[128 + lane], d = rd[192 + lane];
+  double na, nb, nc, nd;
+  bool sing;
+  {  // the row i - stride (one neighbour at a time: four of its values live, not eight)
+    double am = rd[jm], bm = rd[64 + jm], cm = rd[128 + jm], dm = rd[192 + jm];
+    if (!hm) { am = 0.0; bm = 1.0; cm = 0.0; dm = 0.0; }
+    sing = hm && im < n && fabs(bm) < SPICEY_EPS;
+    const double al = -a * spicey_rcp(bm);  // (a = 0 where there is no such neighbour)
+    na = al * am; nb = fma(al, cm, b); nd = fma(al, dm, d);
   }
-  if (lane < n) {  // st == S + 1: the rows are decoupled
-    const double b = rd[64 + lane];
-    if (fabs(b) < SPICEY_EPS && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
-    c.W[(size_t)tab[lane * 4 + 3] * K] = rd[192 + lane] * spicey_rcp(b);
+  {  // the row i + stride
+    double ap = rd[jp], bp = rd[64 + jp], cp = rd[128 + jp], dp = rd[192 + jp];
+    if (!hp) { ap = 0.0; bp = 1.0; cp = 0.0; dp = 0.0; }
+    sing = sing || (hp && ip < n && fabs(bp) < SPICEY_EPS);
+    const double ga = -cc * spicey_rcp(bp);
+    nc = ga * cp; nb = fma(ga, ap, nb); nd = fma(ga, dp, nd);
   }
+  if (st < S) {
+    wr[lane] = na; wr[64 + lane] = nb; wr[128 + lane] = nc; wr[192 + lane] = nd;
+  } else if (lane < n) {  // the rows are decoupled: x = d / b straight into the solution slot
+    sing = sing || fabs(nb) < SPICEY_EPS;
+    c.W[(size_t)tab[lane * 4 + 3] * K] = nd * spicey_rcp(nb);
+  }
+  if (sing && lane < n && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
 }
 
 // The three argument structs hold ~110 pointers: kept in SGPRs across the time loop they overflow the 102 scalar registers
@@ -1170,7 +1186,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
         });
       }
       if (pcr_n > 0) {
-        ex.wave_lockstep(64, pcr_S + 2, [&](int lane, int st) {
+        ex.wave_lockstep(64, pcr_S + 1, [&](int lane, int st) {
           spicey_pcr_stage<K>(c, (double *)c.tail, (const uint16_t *)(c.tail + 1024), pcr_n, pcr_S, lane, st);
         });
       } else if (k_begin > u_end) {
