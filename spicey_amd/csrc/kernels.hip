@@ -32,6 +32,21 @@ __device__ __forceinline__ void gpu_wave_lockstep(int nlanes, int nsteps, F f) {
   __syncthreads();
 }
 
+template <class F>
+__device__ __forceinline__ void gpu_wave_lockstep_keep(int nlanes, int nsteps, F f) {
+  int tid = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  if (tid < 64) {
+    double keep[4] = {0.0, 0.0, 0.0, 0.0};  // per-lane values that live in registers from step to step
+    for (int s = 0; s < nsteps; s++) {
+      if (tid < nlanes) f(tid, s, keep);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+}
+
 struct GpuExec {
   unsigned long long *prof;  // null unless phase profiling was requested
   double *lds_;              // scratch for the dense fronts (null when the program has none)
@@ -316,6 +331,13 @@ struct GpuExecV2 {
     if (prof && threadIdx.x == 0) t0 = clock64();
     gpu_wave_lockstep(nlanes, nsteps, f);
     if (prof && threadIdx.x == 0) atomicAdd(&prof[SPICEY_PH_U0 + 31], (unsigned long long)(clock64() - t0));  // (the slot of the tail it replaces)
+  }
+  template <class F>
+  __device__ __forceinline__ void wave_lockstep_keep(int nlanes, int nsteps, F f) {
+    long long t0 = 0;
+    if (prof && threadIdx.x == 0) t0 = clock64();
+    gpu_wave_lockstep_keep(nlanes, nsteps, f);
+    if (prof && threadIdx.x == 0) atomicAdd(&prof[SPICEY_PH_U0 + 31], (unsigned long long)(clock64() - t0));
   }
   template <class L, class F>
   __device__ __forceinline__ void tail_phase(int tag, int nlev, L load, F f) {

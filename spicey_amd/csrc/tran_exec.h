@@ -1058,40 +1058,39 @@ SPICEY_HD void spicey_pcr_row(const WgCtx<K> &c, const uint16_t *tab, int n, int
   d = on ? vd : 0.0;
 }
 template <int K>
-SPICEY_HD void spicey_pcr_stage(const WgCtx<K> &c, double *buf, const uint16_t *tab, int n, int S, int lane, int st) {
-  const double *rd = buf + (((st - 1) & 1) ? 256 : 0);
+SPICEY_HD void spicey_pcr_stage(const WgCtx<K> &c, double *buf, const uint16_t *tab, int n, int S, int lane, int st, double *own) {
+  // LDS row = {a, 1/b, c, d}: a row forms the reciprocal of its own pivot once, its two neighbours multiply with it;
+  // the row's own {a, b, c, d} stay in registers (`own`) from stage to stage
   double *wr = buf + ((st & 1) ? 256 : 0);
+  bool sing;
   if (st == 0) {  // gather the rows from W (stage 0 writes buffer 0)
     double a, b, cc, d;
     spicey_pcr_row<K>(c, tab, n, lane, a, b, cc, d);
-    wr[lane] = a; wr[64 + lane] = b; wr[128 + lane] = cc; wr[192 + lane] = d;
-    return;
-  }
-  const int h = 1 << (st - 1), im = lane - h, ip = lane + h;
-  const bool hm = im >= 0, hp = ip < 64;
-  const int jm = hm ? im : lane, jp = hp ? ip : lane;
-  const double a = rd[lane], b = rd[64 + lane], cc = rd[128 + lane], d = rd[192 + lane];
-  double na, nb, nc, nd;
-  bool sing;
-  {  // the row i - stride (one neighbour at a time: four of its values live, not eight)
-    double am = rd[jm], bm = rd[64 + jm], cm = rd[128 + jm], dm = rd[192 + jm];
-    if (!hm) { am = 0.0; bm = 1.0; cm = 0.0; dm = 0.0; }
-    sing = hm && im < n && fabs(bm) < SPICEY_EPS;
-    const double al = -a * spicey_rcp(bm);  // (a = 0 where there is no such neighbour)
-    na = al * am; nb = fma(al, cm, b); nd = fma(al, dm, d);
-  }
-  {  // the row i + stride
-    double ap = rd[jp], bp = rd[64 + jp], cp = rd[128 + jp], dp = rd[192 + jp];
-    if (!hp) { ap = 0.0; bp = 1.0; cp = 0.0; dp = 0.0; }
-    sing = sing || (hp && ip < n && fabs(bp) < SPICEY_EPS);
-    const double ga = -cc * spicey_rcp(bp);
-    nc = ga * cp; nb = fma(ga, ap, nb); nd = fma(ga, dp, nd);
-  }
-  if (st < S) {
-    wr[lane] = na; wr[64 + lane] = nb; wr[128 + lane] = nc; wr[192 + lane] = nd;
-  } else if (lane < n) {  // the rows are decoupled: x = d / b straight into the solution slot
-    sing = sing || fabs(nb) < SPICEY_EPS;
-    c.W[(size_t)tab[lane * 4 + 3] * K] = nd * spicey_rcp(nb);
+    own[0] = a; own[1] = b; own[2] = cc; own[3] = d;
+    sing = fabs(b) < SPICEY_EPS;
+    wr[lane] = a; wr[64 + lane] = spicey_rcp(b); wr[128 + lane] = cc; wr[192 + lane] = d;
+  } else {
+    const double *rd = buf + (((st - 1) & 1) ? 256 : 0);
+    const int h = 1 << (st - 1), im = lane - h, ip = lane + h;
+    const bool hm = im >= 0, hp = ip < 64;
+    const int jm = hm ? im : lane, jp = hp ? ip : lane;
+    double am = rd[jm], rm = rd[64 + jm], cm = rd[128 + jm], dm = rd[192 + jm];
+    double ap = rd[jp], rp = rd[64 + jp], cp = rd[128 + jp], dp = rd[192 + jp];
+    if (!hm) { am = 0.0; rm = 1.0; cm = 0.0; dm = 0.0; }
+    if (!hp) { ap = 0.0; rp = 1.0; cp = 0.0; dp = 0.0; }
+    const double al = -own[0] * rm;  // (a = 0 where there is no such neighbour)
+    const double ga = -own[2] * rp;
+    const double na = al * am, nc = ga * cp;
+    const double nb = fma(ga, ap, fma(al, cm, own[1]));
+    const double nd = fma(ga, dp, fma(al, dm, own[3]));
+    sing = fabs(nb) < SPICEY_EPS;
+    const double nr = spicey_rcp(nb);
+    if (st < S) {
+      own[0] = na; own[1] = nb; own[2] = nc; own[3] = nd;
+      wr[lane] = na; wr[64 + lane] = nr; wr[128 + lane] = nc; wr[192 + lane] = nd;
+    } else if (lane < n) {  // the rows are decoupled: x = d / b straight into the solution slot
+      c.W[(size_t)tab[lane * 4 + 3] * K] = nd * nr;
+    }
   }
   if (sing && lane < n && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
 }
@@ -1186,8 +1185,8 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
         });
       }
       if (pcr_n > 0) {
-        ex.wave_lockstep(64, pcr_S + 1, [&](int lane, int st) {
-          spicey_pcr_stage<K>(c, (double *)c.tail, (const uint16_t *)(c.tail + 1024), pcr_n, pcr_S, lane, st);
+        ex.wave_lockstep_keep(64, pcr_S + 1, [&](int lane, int st, double *own) {
+          spicey_pcr_stage<K>(c, (double *)c.tail, (const uint16_t *)(c.tail + 1024), pcr_n, pcr_S, lane, st, own);
         });
       } else if (k_begin > u_end) {
         // the record of level l + 1 is fetched (LDS) while level l executes: one round trip less on the serial chain

@@ -41,6 +41,17 @@ struct SeqExec {
         for (int t = nlanes - 1; t >= 0; t--) f(t, s);
     }
   }
+  // the same with 4 doubles per lane that survive from step to step (registers on the GPU)
+  template <class F>
+  void wave_lockstep_keep(int nlanes, int nsteps, F f) {
+    std::vector<double> keep((size_t)nlanes * 4, 0.0);
+    for (int s = 0; s < nsteps; s++) {
+      if (!reverse)
+        for (int t = 0; t < nlanes; t++) f(t, s, &keep[(size_t)t * 4]);
+      else
+        for (int t = nlanes - 1; t >= 0; t--) f(t, s, &keep[(size_t)t * 4]);
+    }
+  }
   void front_post(unsigned int *, unsigned int) {}
   void front_wait(unsigned int *, unsigned int) {}
   void mark(int) {}
