@@ -94,7 +94,6 @@ typedef struct SpiceyOptions {
                             bit 3 = dense fronts above 64 rows take the staged (global-memory) path even if they fit LDS;
                             bit 4 = AC: never use the resident sweep (one workgroup per (instance, frequency) always);
                             bit 5 = no tridiagonal top (interpreter 2 keeps its task lists for the top levels of a chain);
-                            bit 6 = no chain mode (a circuit that is one tridiagonal system keeps nested dissection + task lists);
                             bits 8.. = extra empty phases per solve */
   int32_t wgs_per_inst;  /* global-workspace path: workgroups (CUs) cooperating on one instance; 0 auto, 1 = none */
   int32_t front_cut;     /* dense fronts (large instances): pivots of elimination-tree level >= front_cut are factored as
@@ -129,9 +128,6 @@ typedef struct SpiceyInfo {
   int64_t front_ws_bytes;   /* front workspace per instance */
   int32_t pcr_rows;         /* interpreter 2: rows of the tridiagonal top solved by one wave with parallel cyclic reduction (0 = none) */
   int32_t pcr_level;        /* first elimination-tree level of that top */
-  int32_t chain_rows;       /* chain mode: rows of the tridiagonal system the whole circuit (minus its sources) reduces to, solved
-                               in place by cyclic reduction; 0 = general program */
-  int32_t chain_levels;     /* its cyclic-reduction levels before the one-wave solver takes the pcr_rows that are left */
 } SpiceyInfo;
 
 typedef struct SpiceyHandle SpiceyHandle;

@@ -131,20 +131,6 @@ struct SpiceyProg {
   // of row i in path order, 0xFFFF = none.
   int32_t pcr_n, pcr_level;
   const uint16_t *pcr_tab;   // [pcr_n][4]
-  // Chain mode (cr_n > 0): EVERYTHING but the voltage sources' node / branch pivots (eliminated first, levels < pcr_level)
-  // is a union of paths = one tridiagonal system of cr_n rows in path order i (structural zeros join the components).
-  // No fill and no task records for it: cr_levels levels of in-place cyclic reduction over the whole workgroup (level l
-  // eliminates the rows i = 2^l - 1 mod 2^(l+1) from their neighbours i -+ 2^l), then the pcr_n <= 64 rows that are left
-  // (i = 2^L - 1 mod 2^L) by the one-wave parallel cyclic reduction above, then the eliminated rows level by level.
-  // Storage: rows are numbered BY THE LEVEL THAT ELIMINATES THEM (block l = cr_off[l] .. cr_off[l+1], in path order inside
-  // a block; the last block = the pcr rows), so that the rows a level reads as neighbours are consecutive in LDS (classic
-  // cyclic reduction strides 2^l and lands every lane on the same bank).  Row at block position p: sub-diagonal W[cr_a0 + p],
-  // diagonal W[cr_b0 + p], super-diagonal W[cr_c0 + p], right-hand side / solution W[cr_d0 + p].
-  int32_t cr_n, cr_levels;
-  int32_t cr_a0, cr_b0, cr_c0, cr_d0;
-  const int32_t *cr_off;     // [cr_levels + 2]
-  int32_t nDynHi;            // v2 B phase: entries [0, nDynHi) may carry dynamic stamps (= nDynEnt unless chain mode numbers
-                             // static entries of the tridiagonal system among them)
 
   // --- dense fronts (nFronts > 0): pivots of elimination-tree level >= front_cut are factored front by front
   //     (multifrontal: assemble from W + children's contribution blocks, blocked dense LU in LDS, trailing update),

@@ -140,12 +140,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   if (front_cut < 0 && desc && desc->n_inst >= 512) front_cut = 0;  // big batches fill the chip with interleaved instances instead
   // tridiagonal top by cyclic reduction (16-bit records, one instance per workgroup); diagnostics: bit 5 = never
   const bool pcr_top = !((h->opt.debug >> 5) & 1) && h->opt.inst_per_wg <= 1;
-  // chain mode (a circuit that is one tridiagonal system once its sources are eliminated; 16-bit interpreter from LDS only);
-  // diagnostics: bit 6 = never
-  const bool chain_mode = pcr_top && !((h->opt.debug >> 6) & 1) && !h->opt.force_global && h->opt.interpreter != 1;
-  int32_t rc = spicey_build_program(desc, h->hp, err, !((h->opt.debug >> 2) & 1), front_cut, pcr_top, chain_mode);  // diagnostics: bit 2 = plain CSR numbering
-  if (rc == SPICEY_OK && h->hp.hdr.cr_n > 0 && spicey_lds_bytes(h->hp.hdr, 1, true) > SPICEY_LDS_MAX)  // does not fit LDS: the general program
-    rc = spicey_build_program(desc, h->hp, err, !((h->opt.debug >> 2) & 1), front_cut, pcr_top, false);
+  int32_t rc = spicey_build_program(desc, h->hp, err, !((h->opt.debug >> 2) & 1), front_cut, pcr_top);  // diagnostics: bit 2 = plain CSR numbering
   if (rc != SPICEY_OK) {
     g_err = err;
     delete h;
@@ -350,15 +345,13 @@ extern "C" int32_t spicey_get_info(SpiceyHandle *h, SpiceyInfo *info) {
   info->streamed_tasks = h->hres.streamed_tasks;
   info->program_bytes = (int64_t)h->hp.blob.size();
   info->algorithmic_bytes_solve = h->algo_bytes;
-  info->factor_reuse = (h->hp.hdr.nD == 0 && h->hp.hdr.nS == 0 && h->hp.hdr.nDynEnt == 0 && !((h->opt.debug >> 1) & 1) && h->hp.hdr.cr_levels == 0) ? 1 : 0;
+  info->factor_reuse = (h->hp.hdr.nD == 0 && h->hp.hdr.nS == 0 && h->hp.hdr.nDynEnt == 0 && !((h->opt.debug >> 1) & 1)) ? 1 : 0;
   info->n_fronts = h->hp.hdr.nFronts;
   info->front_cut = h->hp.hdr.front_cut;
   info->max_front = h->hp.hdr.max_front_mp;
   info->front_ws_bytes = h->hp.hdr.front_ws * (int64_t)sizeof(double);
   info->pcr_rows = (h->interp == 2 && h->K == 1) ? h->hp.hdr.pcr_n : 0;
   info->pcr_level = info->pcr_rows ? h->hp.hdr.pcr_level : 0;
-  info->chain_rows = info->pcr_rows ? h->hp.hdr.cr_n : 0;
-  info->chain_levels = info->chain_rows ? h->hp.hdr.cr_levels : 0;
   return SPICEY_OK;
 }
 

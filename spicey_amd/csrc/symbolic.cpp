@@ -329,7 +329,7 @@ int64_t spicey_algorithmic_bytes(const SpiceyDesc *d, int32_t nnzA, int32_t nnzL
          16 * ((int64_t)d->nC + d->nL + d->nD) + 8 * ((int64_t)d->n_nodes + etot);
 }
 
-static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool slot_major, int front_cut, bool pcr_top, bool chain_mode);
+static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool slot_major, int front_cut, bool pcr_top);
 
 
 // LDS cycles the operand reads of the compact records cost per solve (every half-wave group and operand role: the
@@ -369,21 +369,13 @@ void spicey_bank_cost(const HostProgram &hp, int64_t *cycles, int64_t *ideal) {
 // order.  For programs that run from LDS (16-bit records) both are compiled and the one whose operand reads cost fewer
 // LDS cycles is kept (chains: 2.65 -> 1.88 conflict factor; small meshes are sometimes better off in CSR order).
 // Circuits on the global-workspace path keep the CSR order: LDS banks do not matter there.
-int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware, int front_cut, bool pcr_top, bool chain_mode) {
+int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware, int front_cut, bool pcr_top) {
   hp = HostProgram();
-  if (chain_mode && pcr_top && front_cut <= 0) {
-    // a circuit that is a union of paths once its sources are eliminated: one tridiagonal system, no task lists (see
-    // program.h "chain mode"); such a program runs under the 16-bit interpreter only
-    int32_t rc = build_program_impl(d, hp, err, true, 0, true, true);
-    if (rc != SPICEY_OK) return rc;
-    if (hp.hdr.cr_n > 0 && hp.hdr.has16) return rc;
-    hp = HostProgram();
-  }
-  int32_t rc = build_program_impl(d, hp, err, false, front_cut, pcr_top, false);
+  int32_t rc = build_program_impl(d, hp, err, false, front_cut, pcr_top);
   if (rc != SPICEY_OK || hp.structurally_singular || !hp.hdr.has16 || !bank_aware) return rc;
   HostProgram alt;
   std::string err2;
-  if (build_program_impl(d, alt, err2, true, 0, pcr_top, false) == SPICEY_OK && alt.hdr.has16) {
+  if (build_program_impl(d, alt, err2, true, 0, pcr_top) == SPICEY_OK && alt.hdr.has16) {
     int64_t c0, i0, c1, i1;
     spicey_bank_cost(hp, &c0, &i0);
     spicey_bank_cost(alt, &c1, &i1);
@@ -392,7 +384,7 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
   return rc;
 }
 
-static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, const bool slot_major, int front_cut, const bool pcr_top, const bool chain_mode) {
+static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, const bool slot_major, int front_cut, const bool pcr_top) {
   if (!d) { err = "null descriptor"; return SPICEY_ERR_BAD_DESC; }
   if (d->abi_version != SPICEY_ABI_VERSION) { err = "abi_version mismatch"; return SPICEY_ERR_BAD_DESC; }
   const int nN = d->n_nodes, nR = d->nR, nC = d->nC, nL = d->nL, nV = d->nV, nS = d->nS, nD = d->nD;
@@ -481,7 +473,6 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   // 1 - g/g = 0: `V1 a b / R1 a b / R2 a 0` was reported singular.)
   std::vector<int> row_of_col(n, -1);
   std::vector<int> forced;  // vertices eliminated first: matched nodes of floating sources, then their branch unknowns
-  std::vector<int> forced_all;  // the same for EVERY source (chain mode eliminates all of them first)
   bool structured = true;
   {
     std::vector<int> node_of_src(nV, -1), src_of_node(nN, -1);
@@ -533,8 +524,6 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
         if (term[k][0] >= 0 && term[k][1] >= 0) forced.push_back(node_of_src[k]);
       const size_t nf = forced.size();
       for (size_t i = 0; i < nf; i++) forced.push_back(nN + src_of_node[forced[i]]);
-      for (int k = 0; k < nV; k++) forced_all.push_back(node_of_src[k]);
-      for (int k = 0; k < nV; k++) forced_all.push_back(nN + k);
     }
   }
   // 2b. anything the structured matching cannot express (it fails exactly when sources form a loop or a node hangs on
@@ -556,97 +545,27 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
       if (c2 != c) { g[c].push_back(c2); g[c2].push_back(c); }
   for (int c = 0; c < n; c++) sort_unique(g[c]);
   // the forced vertices leave the graph first (their fill joins their remaining neighbours); nested dissection orders the rest
-  auto eliminate_first = [&](const std::vector<int> &first, Adj &g2, std::vector<char> &gone) {
-    g2 = g;
-    gone.assign(n, 0);
-    for (int v : first) {
-      std::vector<int> nb;
-      for (int w : g2[v])
-        if (!gone[w]) nb.push_back(w);
-      for (int a : nb)
-        for (int b : nb)
-          if (a != b) g2[a].push_back(b);
-      for (int a : nb) sort_unique(g2[a]);
-      gone[v] = 1;
-    }
-  };
-  // 3a. CHAIN MODE (program.h): with every source pair eliminated first, is what remains a union of paths?  Then it is one
-  // tridiagonal system in path order (components joined by structural zeros) and needs neither an ordering nor fill.
-  std::vector<int> chain_path;  // its vertices in path order (empty: not a chain)
-  int crL = 0;                  // levels of cyclic reduction before <= 64 rows are left
-  std::vector<int> cr_off;      // first block position of the rows each level eliminates; [crL] = the rows left, [crL + 1] = nT
-  if (chain_mode && pcr_top && structured && !hp.structurally_singular && n - (int)forced_all.size() >= 3) {
-    Adj gc;
-    std::vector<char> gone;
-    eliminate_first(forced_all, gc, gone);
-    bool ok = true;
-    std::vector<std::vector<int>> nbT(n);
-    for (int v = 0; v < n && ok; v++) {
-      if (gone[v]) continue;
-      for (int w : gc[v])
-        if (!gone[w]) nbT[v].push_back(w);
-      if (nbT[v].size() > 2) ok = false;
-    }
-    std::vector<char> seen(n, 0);
-    std::vector<std::pair<int, int>> joints;  // structural zeros between the end of one component and the start of the next
-    for (int v = 0; v < n && ok; v++) {
-      if (gone[v] || seen[v] || nbT[v].size() > 1) continue;  // walks start at path ends (or isolated vertices)
-      if (!chain_path.empty()) joints.emplace_back(chain_path.back(), v);
-      int prev = -1, cur = v;
-      while (cur >= 0) {
-        seen[cur] = 1;
-        chain_path.push_back(cur);
-        int nxt = -1;
-        for (int w : nbT[cur])
-          if (w != prev && !seen[w]) nxt = w;
-        prev = cur; cur = nxt;
-      }
-    }
-    if (chain_path.size() != (size_t)n - forced_all.size()) ok = false;  // a cycle was never entered
-    if (ok) {
-      joints.emplace_back(chain_path.back(), chain_path.front());  // (closes the band: every row owns a sub- and a super-diagonal slot)
-      for (auto &j : joints) { g[j.first].push_back(j.second); g[j.second].push_back(j.first); }
-      for (auto &j : joints) { sort_unique(g[j.first]); sort_unique(g[j.second]); }
-      const int nT = (int)chain_path.size();
-      while ((nT >> crL) > 64) crL++;
-      cr_off.assign(crL + 2, 0);
-      for (int l = 0; l < crL; l++) cr_off[l + 1] = cr_off[l] + ((nT + (1 << l)) >> (l + 1));  // rows i = 2^l - 1 mod 2^(l+1)
-      cr_off[crL + 1] = nT;
-      if (cr_off[crL] + (nT >> crL) != nT) { err = "internal: cyclic-reduction blocks do not tile the chain"; return SPICEY_ERR_BAD_DESC; }
-      forced = forced_all;
-    } else {
-      chain_path.clear();
-    }
+  Adj g2 = g;
+  std::vector<char> gone(n, 0);
+  for (int v : forced) {
+    std::vector<int> nb;
+    for (int w : g2[v])
+      if (!gone[w]) nb.push_back(w);
+    for (int a : nb)
+      for (int b : nb)
+        if (a != b) g2[a].push_back(b);
+    for (int a : nb) sort_unique(g2[a]);
+    gone[v] = 1;
   }
-  const bool chain = !chain_path.empty();
-  const int nF = (int)forced.size();
-  // block position of the chain row with path index i (numbered by the level that eliminates it, see program.h)
-  auto cr_pos = [&](int i) -> int {
-    int t = 0;
-    while (t < crL && ((i >> t) & 1)) t++;
-    return cr_off[t] + (t < crL ? (i >> (t + 1)) : (i >> crL));
-  };
+  NDOrder nd(g2);
+  for (int v : forced) nd.owner[v] = -1;
+  nd.run();
+  if (nd.order.size() + forced.size() != (size_t)n) { err = "internal: ordering lost vertices"; return SPICEY_ERR_BAD_DESC; }
   hp.cpos.assign(n, -1);
-  if (chain) {
-    int p = 0;
-    for (int v : forced) hp.cpos[v] = p++;
-    for (int i = 0; i < (int)chain_path.size(); i++) hp.cpos[chain_path[i]] = nF + cr_pos(i);
-  } else {
-    Adj g2;
-    std::vector<char> gone;
-    eliminate_first(forced, g2, gone);
-    NDOrder nd(g2);
-    for (int v : forced) nd.owner[v] = -1;
-    nd.run();
-    if (nd.order.size() + forced.size() != (size_t)n) { err = "internal: ordering lost vertices"; return SPICEY_ERR_BAD_DESC; }
+  {
     int p = 0;
     for (int v : forced) hp.cpos[v] = p++;
     for (int v : nd.order) hp.cpos[v] = p++;
-  }
-  std::vector<int> cr_path_of_pos;  // chain mode: pivot position - nF -> path index
-  if (chain) {
-    cr_path_of_pos.assign(chain_path.size(), -1);
-    for (int i = 0; i < (int)chain_path.size(); i++) cr_path_of_pos[cr_pos(i)] = i;
   }
   hp.rpos.assign(n, -1);
   for (int r = 0; r < n; r++) hp.rpos[r] = hp.cpos[col_of_row[r]];
@@ -666,7 +585,6 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
       for (int j : upper[c])
         if (j != k) S.push_back(j);
     sort_unique(S);
-    if (chain && k >= nF) continue;  // chain rows: the band itself (+ what the sources' elimination adds), no fill, no tree
     if (!S.empty()) {
       hp.parent[k] = S[0];
       children[S[0]].push_back(k);
@@ -675,17 +593,10 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   hp.level.assign(n, 0);
   int nLevels = 1;
   for (int k = 0; k < n; k++) {
-    if (chain && k >= nF) break;
     int l = 0;
     for (int c : children[k]) l = std::max(l, hp.level[c] + 1);
     hp.level[k] = l;
     nLevels = std::max(nLevels, l + 1);
-  }
-  int chainL = 0;  // chain mode: the "level" of all chain rows, above every source pivot
-  if (chain) {
-    chainL = nF > 0 ? nLevels : 1;
-    for (int k = nF; k < n; k++) hp.level[k] = chainL;
-    nLevels = chainL + 1;
   }
   // CSR of L+U rows
   EntryIndex E;
@@ -719,29 +630,9 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     };
     mark2(d->S_n1, d->S_n2, nS);
     mark2(d->D_np, d->D_nm, nD);
-    for (int k = 0; k < (chain ? nF : n); k++)
+    for (int k = 0; k < n; k++)
       for (int a : upper[k])
         for (int b : upper[k]) is_tgt[E.pos(a, b)] = 1;
-    // chain mode: the band is reduced in place, every entry of it is restored each step; kind 0 / 1 / 2 = sub-diagonal
-    // (coupling to the path predecessor, cyclically), diagonal, super-diagonal
-    const int nT = chain ? n - nF : 0;
-    auto band_kind = [&](int r, int c) -> int {  // -1: not an entry of the band
-      if (!chain || r < nF || c < nF) return -1;
-      if (r == c) return 1;
-      const int ir = cr_path_of_pos[r - nF], ic = cr_path_of_pos[c - nF];
-      if (ic == (ir + nT - 1) % nT) return 0;
-      if (ic == (ir + 1) % nT) return 2;
-      return -2;  // a coupling the band cannot hold (never happens for a path)
-    };
-    bool band_dyn = false, band_bad = false;
-    if (chain)
-      for (int r = nF; r < n; r++)
-        for (int p = E.ptr[r]; p < E.ptr[r + 1]; p++) {
-          const int kd = band_kind(r, E.col[p]);
-          if (kd == -2) band_bad = true;
-          if (kd >= 0) { is_tgt[p] = 1; band_dyn = band_dyn || is_dyn[p]; }
-        }
-    if (band_bad) { err = "internal: chain mode on a matrix that is not a band"; return SPICEY_ERR_BAD_DESC; }
     // Numbering inside each class: SLOT-MAJOR over the pivots of a level — (level of the owning pivot m = min(row,
     // col), diagonal / L / U, position of the other index in upper[m], m).  The factor tasks of a phase are ordered
     // by (slot pair, pivot), so the 32 lanes of a half-wave read the same slot of 32 consecutive pivots: consecutive
@@ -753,26 +644,15 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
       for (int r = 0; r < n; r++)
         for (int p = E.ptr[r]; p < E.ptr[r + 1]; p++) posr[p] = r;
       std::vector<std::array<int64_t, 2>> key(nLU);
-      int n_cls0 = 0;
       for (int p = 0; p < nLU; p++) {
         const int r = posr[p], c = E.col[p], m = std::min(r, c), o = std::max(r, c);
-        int cls = is_dyn[p] ? 0 : (is_tgt[p] ? 1 : 2);
-        const int bk = band_kind(r, c);
-        if (bk >= 0) {
-          // the band comes first in its class, one array per diagonal in block-position order (a static entry of a band
-          // with any dynamic one rides in the dynamic class: an empty descriptor)
-          cls = band_dyn ? 0 : 1;
-          key[p] = {((int64_t)cls << 44) | ((int64_t)bk << 20), (int64_t)(r - nF)};
-        } else {
-          int64_t slot = 0;
-          if (o != m) slot = std::lower_bound(upper[m].begin(), upper[m].end(), o) - upper[m].begin();
-          const int kind = r == c ? 0 : (c < r ? 1 : 2);
-          if (slot_major) key[p] = {((int64_t)cls << 44) | ((int64_t)1 << 43) | ((int64_t)hp.level[m] << 20) | ((int64_t)kind << 18) | slot, (int64_t)m};
-          else key[p] = {((int64_t)cls << 44) | ((int64_t)1 << 43), (int64_t)p};
-        }
-        n_cls0 += cls == 0 ? 1 : 0;
+        const int cls = is_dyn[p] ? 0 : (is_tgt[p] ? 1 : 2);
+        int64_t slot = 0;
+        if (o != m) slot = std::lower_bound(upper[m].begin(), upper[m].end(), o) - upper[m].begin();
+        const int kind = r == c ? 0 : (c < r ? 1 : 2);
+        if (slot_major) key[p] = {((int64_t)cls << 40) | ((int64_t)hp.level[m] << 20) | ((int64_t)kind << 18) | slot, (int64_t)m};
+        else key[p] = {(int64_t)cls << 40, (int64_t)p};
       }
-      hp.hdr.nDynHi = n_cls0;
       std::vector<int> ordp(nLU);
       std::iota(ordp.begin(), ordp.end(), 0);
       std::stable_sort(ordp.begin(), ordp.end(), [&](int a, int b) { return key[a] < key[b]; });
@@ -787,26 +667,6 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   }
   std::vector<int> diag(n);
   for (int k = 0; k < n; k++) diag[k] = E.find(k, k);
-  hp.hdr.cr_n = 0; hp.hdr.cr_levels = 0;
-  hp.cr_off.clear();
-  if (chain) {
-    // the three diagonals of the band as arrays over the block position
-    const int nT = n - nF;
-    auto at = [&](int p, int kd) {  // entry id of row p's sub- / diagonal / super-diagonal slot
-      const int i = cr_path_of_pos[p];
-      const int j = kd == 1 ? i : (kd == 0 ? (i + nT - 1) % nT : (i + 1) % nT);
-      return E.find(nF + p, nF + cr_pos(j));
-    };
-    hp.hdr.cr_a0 = at(0, 0); hp.hdr.cr_b0 = at(0, 1); hp.hdr.cr_c0 = at(0, 2); hp.hdr.cr_d0 = nLU + nF;
-    for (int p = 0; p < nT; p++)
-      if (at(p, 0) != hp.hdr.cr_a0 + p || at(p, 1) != hp.hdr.cr_b0 + p || at(p, 2) != hp.hdr.cr_c0 + p || hp.hdr.cr_a0 < 0) {
-        err = "internal: the band's entries are not numbered as arrays";
-        return SPICEY_ERR_BAD_DESC;
-      }
-    hp.hdr.cr_n = nT; hp.hdr.cr_levels = crL;
-    hp.cr_off.assign(cr_off.begin(), cr_off.end());
-    front_cut = 0;
-  }
 
   // ---- 4b. dense fronts above the cut (multifrontal upper tree, fronts_exec.h) -------------------------------
   // Pivots of level >= Lc leave the level-scheduled task lists: consecutive pivots whose row structures nest
@@ -1018,7 +878,6 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     struct Prod { uint32_t tgt, l, d, u; };
     std::vector<Prod> prods;
     if (Lc > 0 && l >= Lc) { hp.lvl_slice.push_back((uint32_t)hp.upd_slice.size()); continue; }  // factored as dense fronts
-    if (chain && l >= chainL) { hp.lvl_slice.push_back((uint32_t)hp.upd_slice.size()); continue; }  // reduced in place (16-bit interpreter only)
     for (int k : by_level[l]) {
       const std::vector<int> &S = upper[k];
       for (int a : S) {
@@ -1065,7 +924,6 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     struct Prod { uint32_t tgt, l, d, u; };
     std::vector<Prod> prods;
     if (Lc > 0 && l > Lc) { hp.bk_lvl_slice.push_back((uint32_t)hp.bk_slice.size()); continue; }
-    if (chain && l >= chainL) { hp.bk_lvl_slice.push_back((uint32_t)hp.bk_slice.size()); continue; }
     // with fronts, "level Lc" holds the INTERFACE: every row below the cut receives its products with ALL upper
     // unknowns (solved by the fronts: W[nLU + k] = x[k], diagonal operand = the constant-one slot), highest level first
     const int l_hi = (Lc > 0 && l == Lc) ? nLevels - 1 : l;
@@ -1110,17 +968,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   hp.hdr.pcr_n = 0; hp.hdr.pcr_level = 0;
   std::vector<char> in_top(n, 0);
   int pcrL = 0;
-  if (chain) {
-    // what cyclic reduction leaves (the last block, already in path order) goes to the one-wave solver
-    const int nT = n - nF, m = nT >> crL;
-    for (int k = nF; k < n; k++) in_top[k] = 1;
-    for (int j = 0; j < m; j++) {
-      const int p = cr_off[crL] + j;
-      hp.pcr_tab.push_back((uint16_t)(hp.hdr.cr_a0 + p)); hp.pcr_tab.push_back((uint16_t)(hp.hdr.cr_b0 + p));
-      hp.pcr_tab.push_back((uint16_t)(hp.hdr.cr_c0 + p)); hp.pcr_tab.push_back((uint16_t)(hp.hdr.cr_d0 + p));
-    }
-    hp.hdr.pcr_n = m; hp.hdr.pcr_level = chainL; pcrL = chainL;
-  } else if (pcr_top && hp.hdr.has16 && nLevels >= 4 && !hp.structurally_singular) {
+  if (pcr_top && hp.hdr.has16 && nLevels >= 4 && !hp.structurally_singular) {
     int cnt = 0, L0 = nLevels;
     while (L0 > 1 && cnt + (int)by_level[L0 - 1].size() <= 64) { L0--; cnt += (int)by_level[L0].size(); }  // one row per lane of the solving wave
     if (cnt >= 15 && L0 >= 1 && L0 < nLevels) {
@@ -1278,7 +1126,6 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     if (too_long || hp.ovf16.size() >= (size_t)1 << 31) {  // count field is 8 bits: such circuits use the 32-bit path
       hp.hdr.has16 = 0;
       hp.hdr.pcr_n = 0; hp.hdr.pcr_level = 0; hp.pcr_tab.clear();
-      hp.hdr.cr_n = 0; hp.hdr.cr_levels = 0;  // (the caller rebuilds without chain mode)
       hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear(); hp.ph_rhs.clear();
     }
   }
@@ -1399,7 +1246,6 @@ void HostProgram::pack() {
   add_section(blob, offsets, fr_child);  // 51
   add_section(blob, offsets, fr_rel);    // 52
   add_section(blob, offsets, pcr_tab);   // 53
-  add_section(blob, offsets, cr_off);    // 54
 }
 
 SpiceyProg HostProgram::bind(const void *base) const {
@@ -1423,7 +1269,6 @@ SpiceyProg HostProgram::bind(const void *base) const {
   p.fr = (const SpiceyFront *)(b + offsets[48]);
   p.fr_asm = u32(49); p.fr_bnd = u32(50); p.fr_child = u32(51); p.fr_rel = u32(52);
   p.pcr_tab = (const uint16_t *)(b + offsets[53]);
-  p.cr_off = i32(54);
   return p;
 }
 

@@ -31,7 +31,6 @@ struct HostProgram {
   std::vector<uint32_t> ph_rhs;  // per factor phase: its leading right-hand-side tasks (host only)
   std::vector<uint16_t> ovf16;
   std::vector<uint16_t> pcr_tab;  // tridiagonal top in path order (hdr.pcr_n rows of 4 W indices), see program.h
-  std::vector<int32_t> cr_off;    // chain mode: block offsets of the cyclic-reduction levels (hdr.cr_levels + 2), see program.h
   std::vector<uint32_t> ent_dd, dynx_ent, dynx_ptr, dynx_idx, row_desc, rowx, R_ab, C_ab, L_ab, D_ab;
   std::vector<int32_t> R_a, R_b, C_a, C_b, L_a, L_b, S_a, S_b, S_cp, S_cn, D_a, D_b, V_x, out_x;
   // dense fronts above the cut (empty when hdr.nFronts == 0)
@@ -53,10 +52,7 @@ struct HostProgram {
 // front_cut: elimination-tree level from which pivots are factored as dense fronts (fronts_exec.h); 0 = no fronts,
 // -1 = automatic (large nonlinear circuits only).
 // pcr_top: let the 16-bit records stop below a tridiagonal top that one wave solves by parallel cyclic reduction.
-// chain_mode: where the whole circuit without its sources is a union of paths, build the chain-mode program (program.h):
-// hdr.cr_n > 0, valid for the 16-bit interpreter with one instance per workgroup ONLY (its 32-bit task lists are empty
-// above the sources' levels).  Falls back to the general program by itself where the structure is not a chain.
-int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware = true, int front_cut = 0, bool pcr_top = true, bool chain_mode = false);
+int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware = true, int front_cut = 0, bool pcr_top = true);
 
 // Front schedule for G cooperating workgroups (proportional mapping of the front tree: a subtree's workgroup range is
 // split among its children by work; a front runs on the first workgroup of its range once its children are done).

@@ -643,7 +643,7 @@ struct TranPhases2 {
   typedef ResRegs<K, RMAX, NSV, NEL> Regs;
   SPICEY_HD void set_remainders() {
     brem = (P.nRestore > NSV * T ? 1u : 0u) | (P.nDynX > 0 ? 2u : 0u) | (P.n > NEL * T ? 4u : 0u) | (P.nRowX > 0 ? 8u : 0u) |
-           (P.nDynHi > Regs::NDD * T ? 16u : 0u);
+           (P.nDynEnt > Regs::NDD * T ? 16u : 0u);
     zrem = (P.nOut > NEL * T ? 1u : 0u) | (P.nR > NEL * T ? 2u : 0u) | (P.nC > NEL * T ? 4u : 0u) | (P.nL > 0 ? 8u : 0u) |
            (P.nV > T ? 16u : 0u) | (P.nS > 0 ? 32u : 0u) | (P.nD > NEL * T ? 64u : 0u);
     brem = (uint32_t)SPICEY_UNIFORM((int)brem);
@@ -778,13 +778,13 @@ struct TranPhases2 {
     }
     for (int j = Regs::NDD; j < NSV; j++) {  // plain restores (a dynamic entry this far up is left to the loop below)
       const int e = tid + j * T;
-      if (e >= P.nDynHi && e < P.nRestore)
+      if (e >= P.nDynEnt && e < P.nRestore)
         for (int k = 0; k < K; k++) c.W[(size_t)e * K + k] = rr.sv[j][k];
     }
     SPICEY_MARK(c, 8);
     if (brem & 16u)
     SPICEY_NOUNROLL
-    for (int e = tid + Regs::NDD * T; e < P.nDynHi; e += T) {  // dynamic entries beyond the descriptor slots
+    for (int e = tid + Regs::NDD * T; e < P.nDynEnt; e += T) {  // dynamic entries beyond the descriptor slots
       const uint32_t dd = P.ent_dd[e];
       if (dd >> 31) continue;
       double sv[K];
@@ -794,7 +794,7 @@ struct TranPhases2 {
     if (brem & 1u)
     SPICEY_NOUNROLL
     for (int e = tid + NSV * T; e < P.nRestore; e += T) {  // entries beyond the resident capacity
-      if (e < P.nDynHi) continue;  // done above
+      if (e < P.nDynEnt) continue;  // done above
       const uint32_t dd = P.ent_dd[e];
       if (dd >> 31) continue;
       double sv[K];
@@ -1037,16 +1037,14 @@ struct TranPhases2 {
   }
 };
 
-// ---- tridiagonal top by cyclic reduction in ONE wave (program.h: pcr_n, pcr_tab) --------------------------------------------
-// Lane i = row i of the tridiagonal system (path order); its {a, b, c, d} live in registers (`own`), what its neighbours need
-// — {a, 1/b, c, d} — in one SoA buffer in LDS.  Stage 0 gathers the rows from W through the index table.  Forward stages
-// l = 0 .. F-1 (F = floor(log2 n)): the rows i = 2^(l+1) - 1 mod 2^(l+1) eliminate their couplings to the rows i -+ 2^l, which
-// stop there and keep their equation for the way back; the one row left after F stages is solved.  Backward stages
-// l = F-1 .. 0: the rows stopped at level l take x from the rows i -+ 2^l.  2F + 1 lockstep stages, no workgroup barrier;
-// the backward ones are two LDS reads, two multiply-adds and a store.  This is the elimination order nested dissection
-// gives a path, so the numerics are those of the task lists it replaces (first tried: PARALLEL cyclic reduction, every
-// row through every stage — F + 1 stages of the forward cost, the same time in total, but each x_i comes out of its own
-// chain of F near-cancelling diagonal updates: up to 250 x the error of LU on hard-driven series diodes).
+// ---- tridiagonal top by parallel cyclic reduction (program.h: pcr_n, pcr_tab) -------------------------------------------
+// One wave, lane i = row i of the tridiagonal Schur complement (path order), two SoA buffers {a, b, c, d}[64] in LDS used
+// alternately.  Stage 0 gathers the rows from W through the index table; stage st = 1 .. S (stride 1, 2, 4, ...): row i
+// eliminates its couplings to the rows i -+ stride with those rows' equations; after S = ceil(log2 n) stages every row
+// stands alone and the last stage writes x_i = d_i / b_i straight into the solution slot.
+// Replaces 2 x (S + 1) LDS-serial levels of the task lists; no U entries are formed for these pivots (nothing below needs
+// them: the backward records of lower rows read x only).  All loads of a stage are unconditional (clamped addresses, values
+// masked afterwards) so that they are issued together: one LDS round trip per stage.
 template <int K>
 SPICEY_HD void spicey_pcr_row(const WgCtx<K> &c, const uint16_t *tab, int n, int r, double &a, double &b, double &cc, double &d) {
   const bool on = r >= 0 && r < n;
@@ -1060,122 +1058,41 @@ SPICEY_HD void spicey_pcr_row(const WgCtx<K> &c, const uint16_t *tab, int n, int
   d = on ? vd : 0.0;
 }
 template <int K>
-SPICEY_HD void spicey_pcr_stage(const WgCtx<K> &c, double *buf, const uint16_t *tab, int n, int F, int lane, int st, double *own) {
-  bool sing = false;
-  if (st == 0) {
+SPICEY_HD void spicey_pcr_stage(const WgCtx<K> &c, double *buf, const uint16_t *tab, int n, int S, int lane, int st, double *own) {
+  // LDS row = {a, 1/b, c, d}: a row forms the reciprocal of its own pivot once, its two neighbours multiply with it;
+  // the row's own {a, b, c, d} stay in registers (`own`) from stage to stage
+  double *wr = buf + ((st & 1) ? 256 : 0);
+  bool sing;
+  if (st == 0) {  // gather the rows from W (stage 0 writes buffer 0)
     double a, b, cc, d;
     spicey_pcr_row<K>(c, tab, n, lane, a, b, cc, d);
     own[0] = a; own[1] = b; own[2] = cc; own[3] = d;
     sing = fabs(b) < SPICEY_EPS;
-    buf[lane] = a; buf[64 + lane] = spicey_rcp(b); buf[128 + lane] = cc; buf[192 + lane] = d;
-  } else if (st <= F) {
-    const int h = 1 << (st - 1);
-    if (((lane + 1) & (2 * h - 1)) == 0 && lane < n) {
-      const int im = lane - h, ip = lane + h;
-      const bool hp = ip < n;
-      const int jp = hp ? ip : lane;
-      const double am = buf[im], rm = buf[64 + im], cm = buf[128 + im], dm = buf[192 + im];
-      double ap = buf[jp], rp = buf[64 + jp], cp = buf[128 + jp], dp = buf[192 + jp];
-      if (!hp) { ap = 0.0; rp = 0.0; cp = 0.0; dp = 0.0; }
-      const double al = -own[0] * rm, ga = -own[2] * rp;
-      const double na = al * am, nc = ga * cp;
-      const double nb = fma(ga, ap, fma(al, cm, own[1]));
-      const double nd = fma(ga, dp, fma(al, dm, own[3]));
-      sing = fabs(nb) < SPICEY_EPS;
-      const double nr = spicey_rcp(nb);
-      own[0] = na; own[1] = nb; own[2] = nc; own[3] = nd;
-      buf[lane] = na; buf[64 + lane] = nr; buf[128 + lane] = nc;
-      if (st == F) {  // the last row standing
-        const double x = nd * nr;
-        buf[192 + lane] = x;
-        c.W[(size_t)tab[lane * 4 + 3] * K] = x;
-      } else {
-        buf[192 + lane] = nd;
-      }
-    }
+    wr[lane] = a; wr[64 + lane] = spicey_rcp(b); wr[128 + lane] = cc; wr[192 + lane] = d;
   } else {
-    const int h = 1 << (2 * F - st);
-    if (((lane + 1) & (2 * h - 1)) == h && lane < n) {
-      const int im = lane - h, ip = lane + h;
-      const bool hm = im >= 0, hp = ip < n;
-      double xm = buf[192 + (hm ? im : lane)], xp = buf[192 + (hp ? ip : lane)];
-      const double r = buf[64 + lane];
-      if (!hm) xm = 0.0;
-      if (!hp) xp = 0.0;
-      const double x = fma(-own[2], xp, fma(-own[0], xm, own[3])) * r;
-      buf[192 + lane] = x;
-      c.W[(size_t)tab[lane * 4 + 3] * K] = x;
+    const double *rd = buf + (((st - 1) & 1) ? 256 : 0);
+    const int h = 1 << (st - 1), im = lane - h, ip = lane + h;
+    const bool hm = im >= 0, hp = ip < 64;
+    const int jm = hm ? im : lane, jp = hp ? ip : lane;
+    double am = rd[jm], rm = rd[64 + jm], cm = rd[128 + jm], dm = rd[192 + jm];
+    double ap = rd[jp], rp = rd[64 + jp], cp = rd[128 + jp], dp = rd[192 + jp];
+    if (!hm) { am = 0.0; rm = 1.0; cm = 0.0; dm = 0.0; }
+    if (!hp) { ap = 0.0; rp = 1.0; cp = 0.0; dp = 0.0; }
+    const double al = -own[0] * rm;  // (a = 0 where there is no such neighbour)
+    const double ga = -own[2] * rp;
+    const double na = al * am, nc = ga * cp;
+    const double nb = fma(ga, ap, fma(al, cm, own[1]));
+    const double nd = fma(ga, dp, fma(al, dm, own[3]));
+    sing = fabs(nb) < SPICEY_EPS;
+    const double nr = spicey_rcp(nb);
+    if (st < S) {
+      own[0] = na; own[1] = nb; own[2] = nc; own[3] = nd;
+      wr[lane] = na; wr[64 + lane] = nr; wr[128 + lane] = nc; wr[192 + lane] = nd;
+    } else if (lane < n) {  // the rows are decoupled: x = d / b straight into the solution slot
+      c.W[(size_t)tab[lane * 4 + 3] * K] = nd * nr;
     }
   }
   if (sing && lane < n && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
-}
-
-// ---- chain mode: in-place cyclic reduction of the whole band (program.h: cr_n, cr_levels, cr_off) ----------------------------
-// Block position of the chain row with path index i, known to sit in block >= l1 (its low l1 bits are ones).
-SPICEY_HD int spicey_cr_pos(const SpiceyProg &P, int l1, int i) {
-  const int L = P.cr_levels;
-  int t = l1 + __builtin_ctz(~((unsigned)i >> l1));  // trailing ones of i
-  t = t < L ? t : L;
-  int o = SPICEY_UNIFORM(P.cr_off[l1]);
-  for (int s = l1 + 1; s <= L; s++) {  // (uniform bounds and offsets: a select chain)
-    const int os = SPICEY_UNIFORM(P.cr_off[s]);
-    o = t >= s ? os : o;
-  }
-  return o + (t < L ? (i >> (t + 1)) : (i >> L));
-}
-// Level l forward: every row that survives (path index i = (j + 1) 2^(l+1) - 1) eliminates its couplings to the rows
-// i -+ 2^l — rows j and j + 1 of block l, which this level leaves untouched for the way back.
-template <int K>
-SPICEY_HD void spicey_cr_forward(const WgCtx<K> &c, const SpiceyProg &P, int l, int tid, int T) {
-  const int n = P.cr_n, h2 = 2 << l;
-  const int cnt = n >> (l + 1);
-  const int ol = SPICEY_UNIFORM(P.cr_off[l]), nl = SPICEY_UNIFORM(P.cr_off[l + 1]) - ol;
-  double *A = c.W + (size_t)P.cr_a0 * K, *B = c.W + (size_t)P.cr_b0 * K, *C = c.W + (size_t)P.cr_c0 * K, *D = c.W + (size_t)P.cr_d0 * K;
-  for (int j = tid; j < cnt; j += T) {
-    const int i = (j + 1) * h2 - 1;
-    const int po = spicey_cr_pos(P, l + 1, i), pm = ol + j;
-    const bool hp = j + 1 < nl;  // the last surviving row may have no right neighbour
-    const int pp = hp ? pm + 1 : pm;
-    // (one neighbour at a time: eight values live, not twelve — the two-workgroups-per-CU build has 128 registers)
-    const double a = A[(size_t)po * K], b = B[(size_t)po * K], cc = C[(size_t)po * K], d = D[(size_t)po * K];
-    double na, nb, nc, nd;
-    bool sing;
-    {
-      const double am = A[(size_t)pm * K], bm = B[(size_t)pm * K], cm = C[(size_t)pm * K], dm = D[(size_t)pm * K];
-      sing = fabs(bm) < SPICEY_EPS;
-      const double al = -a * spicey_rcp(bm);
-      na = al * am; nb = fma(al, cm, b); nd = fma(al, dm, d);
-    }
-    SPICEY_SCHED_FENCE;
-    {
-      double ap = A[(size_t)pp * K], bp = B[(size_t)pp * K], cp = C[(size_t)pp * K], dp = D[(size_t)pp * K];
-      if (!hp) { ap = 0.0; bp = 1.0; cp = 0.0; dp = 0.0; }
-      sing = sing || fabs(bp) < SPICEY_EPS;
-      const double ga = hp ? -cc * spicey_rcp(bp) : 0.0;
-      nc = ga * cp; nb = fma(ga, ap, nb); nd = fma(ga, dp, nd);
-    }
-    A[(size_t)po * K] = na; B[(size_t)po * K] = nb; C[(size_t)po * K] = nc; D[(size_t)po * K] = nd;
-    if (sing && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
-  }
-}
-// Level l backward: the rows of block l (path index i = q 2^(l+1) + 2^l - 1), from the solved rows i -+ 2^l.
-template <int K>
-SPICEY_HD void spicey_cr_backward(const WgCtx<K> &c, const SpiceyProg &P, int l, int tid, int T) {
-  const int n = P.cr_n, h = 1 << l;
-  const int ol = SPICEY_UNIFORM(P.cr_off[l]), nl = SPICEY_UNIFORM(P.cr_off[l + 1]) - ol;
-  const double *A = c.W + (size_t)P.cr_a0 * K, *B = c.W + (size_t)P.cr_b0 * K, *C = c.W + (size_t)P.cr_c0 * K;
-  double *D = c.W + (size_t)P.cr_d0 * K;
-  for (int q = tid; q < nl; q += T) {
-    const int i = q * 2 * h + h - 1, p = ol + q;
-    const bool hm = q > 0, hp = i + h < n;
-    const int pm = hm ? spicey_cr_pos(P, l + 1, i - h) : p, pp = hp ? spicey_cr_pos(P, l + 1, i + h) : p;
-    const double a = A[(size_t)p * K], b = B[(size_t)p * K], cc = C[(size_t)p * K], d = D[(size_t)p * K];
-    double xm = D[(size_t)pm * K], xp = D[(size_t)pp * K];
-    if (!hm) xm = 0.0;
-    if (!hp) xp = 0.0;
-    if (fabs(b) < SPICEY_EPS && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
-    D[(size_t)p * K] = fma(-cc, xp, fma(-a, xm, d)) * spicey_rcp(b);
-  }
 }
 
 // The three argument structs hold ~110 pointers: kept in SGPRs across the time loop they overflow the 102 scalar registers
@@ -1231,16 +1148,9 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
     if (SPICEY_UNIFORM((int)Q.st_cnt[p]) != 0) smask |= 1ull << p;
   }
   const int tail_n = Q.tail_n, tail_first = Q.tail_first;
-  // (the tridiagonal solvers' three loop-control values ride in ONE scalar across the time loop and are unpacked inside
-  // it: every further live scalar there costs a lane of a spill VGPR, and the 128-register build has none to give)
-  int top_pack;
-  {
-    const int n0 = K == 1 ? P.pcr_n : 0;
-    int S0 = 0;  // forward stages of the one-wave cyclic reduction: floor(log2 n)
-    while ((2 << S0) <= n0) S0++;
-    top_pack = n0 | (S0 << 8) | ((K == 1 && P.cr_n > 0 ? P.cr_levels : 0) << 16);
-  }
-  const int pcr_n = top_pack & 0xff;
+  const int pcr_n = K == 1 ? P.pcr_n : 0;
+  int pcr_S = 0;
+  while ((1 << pcr_S) < pcr_n) pcr_S++;
   // with a tridiagonal top the factor phases end at its level and the backward phases resume below it
   const int u_end = pcr_n > 0 ? P.pcr_level : (tail_n > 0 ? tail_first : nL);
   const int k_begin = pcr_n > 0 ? 2 * nL - P.pcr_level : (tail_n > 0 ? tail_first + tail_n : nL);
@@ -1248,13 +1158,10 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
   // No diodes and no switches: the matrix of every step is the matrix of step 0 (dt is fixed within a run), so its
   // factors stay in W and later steps run the right-hand-side column only.  Same operands, same order: the results
   // are bit-identical to refactoring (SURVEY.md §8(d) "solve-only" rate; the reference itself never reuses).
-  const bool linear = P.nD == 0 && nS == 0 && P.nDynEnt == 0 && !R.no_reuse && (top_pack >> 16) == 0;  // (cyclic reduction works in place)
+  const bool linear = P.nD == 0 && nS == 0 && P.nDynEnt == 0 && !R.no_reuse;
   for (int64_t step = 0; step <= steps && code == 0; step++) {
     int iter = 0;
     for (;;) {
-      int tp = top_pack;
-      SPICEY_OPAQUE_S(tp);
-      const int pcr_n = tp & 0xff, pcr_S = (tp >> 8) & 0xff, cr_L = tp >> 16;
       ex.phase(SPICEY_PH_B, [&](int tid) {
         const SpiceyProg Pf = ex.fresh(P);
         const SpiceyRun Rf = ex.fresh(R);
@@ -1277,13 +1184,8 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
           spicey_uk_phase<K, RMAX, NSV, NEL, false>(Pf, Qf, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true, linear && step > 0);
         });
       }
-      for (int l = 0; l < cr_L; l++)  // chain mode: the whole band, level by level, down to the rows one wave takes
-        ex.phase(SPICEY_PH_U0 + (u_end + l < 30 ? u_end + l : 30), [&](int tid) {
-          const SpiceyProg Pf = ex.fresh(P);
-          spicey_cr_forward<K>(c, Pf, l, tid, T);
-        });
       if (pcr_n > 0) {
-        ex.wave_lockstep_keep(64, 2 * pcr_S + 1, [&](int lane, int st, double *own) {
+        ex.wave_lockstep_keep(64, pcr_S + 1, [&](int lane, int st, double *own) {
           spicey_pcr_stage<K>(c, (double *)c.tail, (const uint16_t *)(c.tail + 1024), pcr_n, pcr_S, lane, st, own);
         });
       } else if (k_begin > u_end) {
@@ -1299,11 +1201,6 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
                         else spicey_exec_rec16<K, true>(c, Pf.ovf16, r[0], r[1], r[2], r[3]);
                       });
       }
-      for (int l = cr_L - 1; l >= 0; l--)
-        ex.phase(SPICEY_PH_K0 + (u_end + l < 31 ? u_end + l : 31), [&](int tid) {
-          const SpiceyProg Pf = ex.fresh(P);
-          spicey_cr_backward<K>(c, Pf, l, tid, T);
-        });
       for (int p = k_begin; p < 2 * nL - 1; p++) {
         const int l = 2 * nL - 1 - p;
         ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) {

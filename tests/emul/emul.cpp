@@ -140,8 +140,7 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
   std::string err;
   const int front_cut = reverse >> 8;  // bits 8..: elimination-tree level from which pivots are factored as dense fronts
   // bit 4: no tridiagonal top (the 16-bit records then cover every level); interleaved instances (K > 1) never use it
-  // bit 5: no chain mode (v2, K = 1 takes it wherever the circuit is a chain: the 32-bit lists of such a program are empty)
-  int32_t rc = spicey_build_program(d, hp, err, true, front_cut, !(reverse & 16) && K == 1, !(reverse & 48) && K == 1 && rmax >= 0);
+  int32_t rc = spicey_build_program(d, hp, err, true, front_cut, !(reverse & 16) && K == 1);
   if (rc != SPICEY_OK) return rc;
   SpiceyProg P = hp.bind(hp.blob.data());
   if (info) {
@@ -153,8 +152,6 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
     info->n_workgroups = (d->n_inst + K - 1) / K;
     info->pcr_rows = (rmax >= 0 && K == 1) ? P.pcr_n : 0;
     info->pcr_level = info->pcr_rows ? P.pcr_level : 0;
-    info->chain_rows = info->pcr_rows ? P.cr_n : 0;
-    info->chain_levels = info->chain_rows ? P.cr_levels : 0;
   }
   if (hp.structurally_singular) {
     if (err4) { err4[0] = 1; err4[1] = 0; err4[2] = 0; err4[3] = 0; }
