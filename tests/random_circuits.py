@@ -103,3 +103,27 @@ def random_netlist(seed: int, max_nodes: int = 10, floating_sources: bool = Fals
     lines.append(f".tran 1e-6 {rnd.choice(['2e-5', '1.5e-5', '3e-5'])}")
     lines.append(".end")
     return "\n".join(lines)
+
+
+def series_diode_chain(seed: int, n: int) -> str:
+    """A chain whose links are diodes (either direction) or small resistors, driven hard (up to 200 V): conducting series
+    diodes couple neighbouring rows far more strongly than anything ties them to ground — the weakly diagonally dominant
+    case that separates elimination orders numerically (the tridiagonal top's cyclic reduction against LU)."""
+    rng = random.Random(1000 + seed)
+    amp = 10 ** rng.uniform(0, 2.3)
+    lines = [f"* series diode chain seed {seed}", ".model DM D(Is=1e-14 N=1)", f"V1 n1 0 PULSE(0 {amp:.4g} 0 1e-6 1e-6 5e-6 2e-5)"]
+    for k in range(1, n):
+        u = rng.random()
+        if u < 0.45:
+            lines.append(f"D{k} n{k} n{k+1} DM")
+        elif u < 0.55:
+            lines.append(f"D{k} n{k+1} n{k} DM")
+        else:
+            lines.append(f"RS{k} n{k} n{k+1} {10 ** rng.uniform(0, 4):.5g}")
+        lines.append(f"R{k} n{k+1} 0 {10 ** rng.uniform(1, 5):.5g}")
+        if rng.random() < 0.7:
+            lines.append(f"C{k} n{k+1} 0 {10 ** rng.uniform(-10, -7):.4g}")
+        if rng.random() < 0.2:
+            lines.append(f"DG{k} n{k+1} 0 DM")
+    lines += [".tran 1e-6 2.5e-5", ".end", ""]
+    return "\n".join(lines)
