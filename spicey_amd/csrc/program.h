@@ -28,6 +28,7 @@
 #define SPICEY_R16_VALID 0x80u
 #define SPICEY_R16_RECIP 0x02u
 #define SPICEY_R16_K 0x01u
+#define SPICEY_R16_FUSED 0x04u  // a ROW record of two 16-byte halves (fus16, below)
 
 // Dense front of the upper elimination tree (large instances, fronts_exec.h): a supernode — `p` consecutive pivots
 // whose rows share one structure — with its `q` boundary unknowns, stored as a dense (Mp x ld) row-major block of the
@@ -124,6 +125,17 @@ struct SpiceyProg {
   const uint32_t *ph_cnt;    // [2 nLevels]
   int32_t nRec16;
   int32_t has16;             // 0 when nW >= 65536 (global-workspace path only)
+  // Row records (second encoding of a factor phase, used where the phase is STREAMED).  On ladders / chains a target row i
+  // of a level receives from at most two pivots k, each with at most one other neighbour o_k: its four targets
+  // (a_ii, y_i, a_i,o1, a_i,o2) share the multipliers -(L_ik d_k) and most operands, yet the generic encoding runs them
+  // as four tasks (22 operand reads, ~160 instructions against 14 and ~70).  fus16 holds, per factor phase p with
+  // fus_pairs[p] > 0: fus_gen[p] generic 16-byte records (the tasks of rows that do not fit the pattern; the first
+  // fus_rhs[p] are the right-hand-side ones) followed by fus_pairs[p] 32-byte row records, starting at 16-byte unit
+  // fus_first[p].  Row record, 16 u16: [0] a_ii  [1] meta = pivots (1|2) | has_o1 << 4 | has_o2 << 5 | flags << 8
+  // (VALID | FUSED | RECIP)  [2] y_i  then per pivot k: L_ik, d_k, U_ki, y_k, U_k,o, a_i,o  [15] spare.
+  // Same products in the same order as the generic tasks: bit-identical results.
+  const uint32_t *fus16;
+  const uint32_t *fus_first, *fus_gen, *fus_rhs, *fus_pairs;  // [nLevels]
   // Tridiagonal top (16-bit records only): when the <= 64 pivots of level >= pcr_level see each other, after the levels
   // below are eliminated, only along a PATH (ladders, chains, lines), their Schur complement is tridiagonal and one wave
   // solves it by parallel cyclic reduction (log2 steps, no factor / backward levels above pcr_level: their phases hold no
@@ -155,6 +167,7 @@ struct SpiceyProg {
 // did not fit stay streamed: st_first/st_cnt index rec16.
 struct SpiceyResident {
   const uint32_t *st_rhs;  // [2L] leading right-hand-side tasks of a streamed factor phase (the only ones a reused factorisation runs)
+  const uint32_t *st_fus;  // [2L] 1: this streamed factor phase runs from its row-record encoding (SpiceyProg::fus16)
   const uint32_t *res;        // [RMAX][T][4]
   const int32_t *res_phase;   // [T/64][RMAX]
   const uint32_t *st_first;   // [2 nLevels]

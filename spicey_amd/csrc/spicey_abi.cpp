@@ -221,7 +221,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
     const size_t lds_cap = h->packed ? SPICEY_LDS_MAX / 2 : SPICEY_LDS_MAX;
     int max_tail = (int)std::min<size_t>(24, base < lds_cap ? (lds_cap - base) / 1024 : 0);
     if (h->opt.debug & 1) max_tail = 0;  // diagnostics: disable the tail merge
-    spicey_build_resident(h->hp, h->T, spicey_v2_rmax(h->T, h->packed), h->hres, max_tail);
+    spicey_build_resident(h->hp, h->T, spicey_v2_rmax(h->T, h->packed), h->hres, max_tail, !((h->opt.debug >> 6) & 1));  // diagnostics: bit 6 = no row records
     h->lds_bytes = spicey_lds_bytes(P, K, true, h->hres.tail_n);
   }
 

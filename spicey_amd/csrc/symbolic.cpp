@@ -960,6 +960,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
 
   // ---- 5c'. compact 16-bit records of the same tasks, phases in execution order -------------------
   hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear(); hp.ph_rhs.clear();
+  hp.fus16.clear(); hp.fus_first.assign(nLevels, 0u); hp.fus_gen.assign(nLevels, 0u); hp.fus_rhs.assign(nLevels, 0u); hp.fus_pairs.assign(nLevels, 0u);
   hp.hdr.has16 = ((nLU + n) < 65535 && Lc == 0) ? 1 : 0;  // 0xFFFF = ground in the packed terminal words; fronts run under the 32-bit interpreter
   // Tridiagonal top: T = the pivots of the highest levels, at most 64 of them (one row per lane of a wave).  Two of them are coupled, once everything
   // below is eliminated, iff the original matrix couples them or some lower pivot has both in its row structure.  If that
@@ -1028,7 +1029,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   }
   if (pcrL == 0) std::fill(in_top.begin(), in_top.end(), 0);
   if (hp.hdr.has16) {
-    auto emit_u = [&](uint32_t tgt, bool recip, const std::vector<uint32_t> &tr) {  // tr = (l,d,u)*
+    auto emit_u = [&](uint32_t tgt, bool recip, const std::vector<uint32_t> &tr, std::vector<uint32_t> &dst) {  // tr = (l,d,u)*
       const uint32_t cnt = (uint32_t)(tr.size() / 3);
       uint32_t flags = SPICEY_R16_VALID | (recip ? SPICEY_R16_RECIP : 0u);
       uint32_t w0 = tgt | ((std::min(cnt, 255u) | (flags << 8)) << 16), w1 = 0, w2 = 0, w3 = 0;
@@ -1039,7 +1040,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
         w3 = (uint32_t)hp.ovf16.size();
         for (uint32_t v : tr) hp.ovf16.push_back((uint16_t)v);
       }
-      hp.rec16.insert(hp.rec16.end(), {w0, w1, w2, w3});
+      dst.insert(dst.end(), {w0, w1, w2, w3});
     };
     auto emit_k = [&](uint32_t x, uint32_t dg, const std::vector<uint32_t> &pr) {  // pr = (u,xb)*
       const uint32_t cnt = (uint32_t)(pr.size() / 2);
@@ -1107,8 +1108,60 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
       uint32_t nrhs = 0;
       for (auto &u : uts) nrhs += (int)u.t >= nLU ? 1u : 0u;
       hp.ph_rhs.push_back(nrhs);
-      for (auto &u : uts) emit_u(u.t, u.recip, u.tr);
+      for (auto &u : uts) emit_u(u.t, u.recip, u.tr, hp.rec16);
       hp.ph_cnt.push_back((uint32_t)(hp.rec16.size() / 4) - hp.ph_first.back());
+      // ---- the same phase as row records (program.h: fus16) -------------------------------------------------------------
+      {
+        // pivots of this level that reach row a; a row fits if it has <= 2 of them, each with <= 2 neighbours, and the
+        // neighbours on the far side are distinct
+        std::vector<std::vector<int>> reach(n);
+        for (int k : by_level[l])
+          for (int a : upper[k]) reach[a].push_back(k);
+        auto other = [&](int k, int a) -> int {  // the neighbour of pivot k that is not a (-1: none)
+          for (int b : upper[k]) if (b != a) return b;
+          return -1;
+        };
+        std::vector<char> fits(n, 0);
+        std::vector<int> rows;
+        for (int a = 0; a < n; a++) {
+          if (reach[a].empty() || reach[a].size() > 2) continue;
+          bool ok = true;
+          for (int k : reach[a]) ok = ok && upper[k].size() <= 2;
+          if (ok && reach[a].size() == 2) {
+            const int o0 = other(reach[a][0], a), o1 = other(reach[a][1], a);
+            if (o0 >= 0 && o0 == o1) ok = false;
+          }
+          if (ok) { fits[a] = 1; rows.push_back(a); }
+        }
+        if (rows.size() >= 64) {  // (fewer: not worth a second encoding)
+          hp.fus_first[l] = (uint32_t)(hp.fus16.size() / 4);
+          uint32_t ngen = 0, ngrhs = 0;
+          for (auto &u : uts) {
+            const int row = (int)u.t >= nLU ? (int)u.t - nLU : E.row_of_id[u.t];
+            if (fits[row]) continue;
+            emit_u(u.t, u.recip, u.tr, hp.fus16);
+            ngen++;
+            ngrhs += (int)u.t >= nLU ? 1u : 0u;
+          }
+          hp.fus_gen[l] = ngen; hp.fus_rhs[l] = ngrhs;
+          for (int a : rows) {
+            std::sort(reach[a].begin(), reach[a].end());
+            uint16_t h[16] = {0};
+            const bool recip = hp.level[a] == l + 1 && !in_top[a];
+            uint32_t meta = (uint32_t)reach[a].size() | ((SPICEY_R16_VALID | SPICEY_R16_FUSED | (recip ? SPICEY_R16_RECIP : 0u)) << 8);
+            h[0] = (uint16_t)diag[a]; h[2] = (uint16_t)(nLU + a);
+            for (size_t i = 0; i < reach[a].size(); i++) {
+              const int k = reach[a][i], o = other(k, a);
+              uint16_t *q = h + 3 + 6 * i;
+              q[0] = (uint16_t)E.find(a, k); q[1] = (uint16_t)diag[k]; q[2] = (uint16_t)E.find(k, a); q[3] = (uint16_t)(nLU + k);
+              if (o >= 0) { q[4] = (uint16_t)E.find(k, o); q[5] = (uint16_t)E.find(a, o); meta |= 1u << (4 + i); }
+            }
+            h[1] = (uint16_t)meta;
+            for (int w = 0; w < 8; w++) hp.fus16.push_back((uint32_t)h[2 * w] | ((uint32_t)h[2 * w + 1] << 16));
+          }
+          hp.fus_pairs[l] = (uint32_t)rows.size();
+        }
+      }
     }
     for (int l = nLevels - 1; l >= 0; l--) {  // backward phases, top level first
       hp.ph_first.push_back((uint32_t)(hp.rec16.size() / 4));
@@ -1125,6 +1178,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     }
     if (too_long || hp.ovf16.size() >= (size_t)1 << 31) {  // count field is 8 bits: such circuits use the 32-bit path
       hp.hdr.has16 = 0;
+      hp.fus16.clear(); std::fill(hp.fus_pairs.begin(), hp.fus_pairs.end(), 0u);
       hp.hdr.pcr_n = 0; hp.hdr.pcr_level = 0; hp.pcr_tab.clear();
       hp.rec16.clear(); hp.ovf16.clear(); hp.ph_first.clear(); hp.ph_cnt.clear(); hp.ph_rhs.clear();
     }
@@ -1246,6 +1300,9 @@ void HostProgram::pack() {
   add_section(blob, offsets, fr_child);  // 51
   add_section(blob, offsets, fr_rel);    // 52
   add_section(blob, offsets, pcr_tab);   // 53
+  add_section(blob, offsets, fus16);     // 54
+  add_section(blob, offsets, fus_first); add_section(blob, offsets, fus_gen);    // 55 56
+  add_section(blob, offsets, fus_rhs); add_section(blob, offsets, fus_pairs);    // 57 58
 }
 
 SpiceyProg HostProgram::bind(const void *base) const {
@@ -1269,13 +1326,14 @@ SpiceyProg HostProgram::bind(const void *base) const {
   p.fr = (const SpiceyFront *)(b + offsets[48]);
   p.fr_asm = u32(49); p.fr_bnd = u32(50); p.fr_child = u32(51); p.fr_rel = u32(52);
   p.pcr_tab = (const uint16_t *)(b + offsets[53]);
+  p.fus16 = u32(54); p.fus_first = u32(55); p.fus_gen = u32(56); p.fus_rhs = u32(57); p.fus_pairs = u32(58);
   return p;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Resident layout: chunks of 64 lanes; chunk c lives in (wave c % nWaves, slot c / nWaves), so the
 // chunks of one phase spread over the waves.  Smallest phases first (they are pure latency).
-void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident &out, int max_tail) {
+void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident &out, int max_tail, bool row_records) {
   out = HostResident();
   out.rmax = rmax; out.T = T;
   const int nPh = (int)hp.ph_cnt.size();
@@ -1285,6 +1343,7 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
   out.st_first.assign(std::max(nPh, 1), 0u);
   out.st_cnt.assign(std::max(nPh, 1), 0u);
   out.st_rhs.assign(std::max(nPh, 1), 0u);
+  out.st_fus.assign(std::max(nPh, 1), 0u);
   if (hp.hdr.has16 && nPh <= 254 && max_tail > 1 && hp.hdr.pcr_n == 0) {  // (a tridiagonal top replaces the tail: its phases hold no records)
     // tail: longest run of <= 64-task phases around the factor -> backward turn (phase nLevels-1 | nLevels)
     const int nL = hp.hdr.nLevels;
@@ -1318,6 +1377,9 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
         out.st_first[p] = hp.ph_first[p];
         out.st_cnt[p] = hp.ph_cnt[p];
         out.st_rhs[p] = p < (int)hp.ph_rhs.size() ? hp.ph_rhs[p] : hp.ph_cnt[p];
+        // streamed anyway: take the row records — where they keep most threads busy (a level with fewer rows than half the
+        // workgroup is latency-bound on the one exposed record fetch; its generic records, several per thread, overlap theirs)
+        out.st_fus[p] = (row_records && p < (int)hp.fus_pairs.size() && 2 * (int)hp.fus_pairs[p] > T) ? 1u : 0u;
         out.streamed_tasks += cnt;
         continue;
       }
@@ -1359,6 +1421,7 @@ void HostResident::pack() {
   add_section(blob, offsets, st_first);
   add_section(blob, offsets, st_cnt);
   add_section(blob, offsets, st_rhs);
+  add_section(blob, offsets, st_fus);
 }
 
 SpiceyResident HostResident::bind(const void *base) const {
@@ -1369,6 +1432,7 @@ SpiceyResident HostResident::bind(const void *base) const {
   r.st_first = (const uint32_t *)(b + offsets[2]);
   r.st_cnt = (const uint32_t *)(b + offsets[3]);
   r.st_rhs = (const uint32_t *)(b + offsets[4]);
+  r.st_fus = (const uint32_t *)(b + offsets[5]);
   r.rmax = rmax;
   r.T = T;
   r.tail_first = tail_first;

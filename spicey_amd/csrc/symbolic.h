@@ -30,6 +30,7 @@ struct HostProgram {
   std::vector<uint32_t> rec16, ph_first, ph_cnt;  // compact records (has16)
   std::vector<uint32_t> ph_rhs;  // per factor phase: its leading right-hand-side tasks (host only)
   std::vector<uint16_t> ovf16;
+  std::vector<uint32_t> fus16, fus_first, fus_gen, fus_rhs, fus_pairs;  // row-record encoding of the factor phases (program.h)
   std::vector<uint16_t> pcr_tab;  // tridiagonal top in path order (hdr.pcr_n rows of 4 W indices), see program.h
   std::vector<uint32_t> ent_dd, dynx_ent, dynx_ptr, dynx_idx, row_desc, rowx, R_ab, C_ab, L_ab, D_ab;
   std::vector<int32_t> R_a, R_b, C_a, C_b, L_a, L_b, S_a, S_b, S_cp, S_cn, D_a, D_b, V_x, out_x;
@@ -66,7 +67,7 @@ void spicey_bank_cost(const HostProgram &hp, int64_t *cycles, int64_t *ideal);
 // Resident (register) layout of the compact records for a workgroup of T threads with `rmax` slots per
 // thread.  Blob sections: res[rmax][T][4] u32, res_phase[T/64][rmax] i32, st_first[2L] u32, st_cnt[2L] u32.
 struct HostResident {
-  std::vector<uint32_t> res, st_first, st_cnt, st_rhs;
+  std::vector<uint32_t> res, st_first, st_cnt, st_rhs, st_fus;
   std::vector<int32_t> res_phase;
   int rmax = 0, T = 0, tail_first = 0, tail_n = 0;
   int64_t resident_tasks = 0, streamed_tasks = 0;
@@ -75,7 +76,8 @@ struct HostResident {
   void pack();
   SpiceyResident bind(const void *base) const;
 };
-void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident &out, int max_tail = 0);
+// row_records: streamed factor phases that have a row-record encoding (program.h: fus16) run from it
+void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident &out, int max_tail = 0, bool row_records = true);
 
 // SURVEY.md §8(d) algorithmic bytes per solve.
 int64_t spicey_algorithmic_bytes(const SpiceyDesc *d, int32_t nnzA, int32_t nnzLU);

@@ -567,6 +567,46 @@ SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_
   }
 }
 
+// One ROW record of a factor phase (program.h: fus16): the targets a_ii, y_i and the (at most two) fills of row i from its
+// (at most two) pivots of this level, sharing the multipliers -(L_ik d_k).  The products and their order are those of the
+// generic tasks it stands for.  rhs_only: a reused factorisation updates y_i alone.
+template <int K>
+SPICEY_HD void spicey_exec_row16(const WgCtx<K> &c, const uint32_t *w, bool rhs_only) {
+  const uint32_t meta = w[0] >> 16;
+  if (!(meta & (SPICEY_R16_VALID << 8))) return;
+  const uint32_t iaa = w[0] & 0xffffu, iy = w[1] & 0xffffu;
+  const uint32_t l0 = w[1] >> 16, d0 = w[2] & 0xffffu, u0 = w[2] >> 16, y0 = w[3] & 0xffffu, f0 = w[3] >> 16, t0 = w[4] & 0xffffu;
+  const uint32_t l1 = w[4] >> 16, d1 = w[5] & 0xffffu, u1 = w[5] >> 16, y1 = w[6] & 0xffffu, f1 = w[6] >> 16, t1 = w[7] & 0xffffu;
+  const bool two = (meta & 3u) == 2u, o0 = (meta >> 4) & 1u, o1 = (meta >> 5) & 1u;
+  for (int k = 0; k < K; k++) {
+    double aii = c.W[(size_t)iaa * K + k], yi = c.W[(size_t)iy * K + k];
+    {
+      const double m = -(c.W[(size_t)l0 * K + k] * c.W[(size_t)d0 * K + k]);
+      const double vy = c.W[(size_t)y0 * K + k], vu = c.W[(size_t)u0 * K + k], vf = c.W[(size_t)f0 * K + k], vt = c.W[(size_t)t0 * K + k];
+      yi = fma(m, vy, yi);
+      aii = fma(m, vu, aii);
+      if (o0 && !rhs_only) c.W[(size_t)t0 * K + k] = fma(m, vf, vt);
+    }
+    SPICEY_SCHED_FENCE;
+    {  // (unused second pivot: indices 0, valid addresses; the results are masked)
+      const double m = -(c.W[(size_t)l1 * K + k] * c.W[(size_t)d1 * K + k]);
+      const double vy = c.W[(size_t)y1 * K + k], vu = c.W[(size_t)u1 * K + k], vf = c.W[(size_t)f1 * K + k], vt = c.W[(size_t)t1 * K + k];
+      const double y2 = fma(m, vy, yi), a2 = fma(m, vu, aii);
+      yi = two ? y2 : yi;
+      aii = two ? a2 : aii;
+      if (two && o1 && !rhs_only) c.W[(size_t)t1 * K + k] = fma(m, vf, vt);
+    }
+    c.W[(size_t)iy * K + k] = yi;
+    if (!rhs_only) {
+      if (meta & (SPICEY_R16_RECIP << 8)) {
+        if (fabs(aii) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
+        aii = spicey_rcp(aii);
+      }
+      c.W[(size_t)iaa * K + k] = aii;
+    }
+  }
+}
+
 template <int K, int RMAX, int NSV, int NEL, bool KTASK>
 SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, const WgCtx<K> &c, ResRegs<K, RMAX, NSV, NEL> &rr, int tid,
                                int T, int p, bool streamed, bool reuse = false) {
@@ -601,12 +641,27 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
     rr.cursor = q;
   }
   if (!streamed) return;
-  const uint32_t sc = (!KTASK && reuse) ? Q.st_rhs[p] : Q.st_cnt[p];  // right-hand-side tasks lead every factor phase
+  uint32_t sc = (!KTASK && reuse) ? Q.st_rhs[p] : Q.st_cnt[p];  // right-hand-side tasks lead every factor phase
+  const uint32_t *base = P.rec16 + (size_t)Q.st_first[p] * 4;
+  if (!KTASK && sc && Q.st_fus[p]) {
+    // the phase's row-record encoding: its 32-byte row records (one per thread on the chains this is for), then the few
+    // generic records of rows that do not fit the pattern
+    const uint32_t *fb = P.fus16 + (size_t)P.fus_first[p] * 4;
+    const uint32_t ngen = P.fus_gen[p], npair = P.fus_pairs[p];
+    const uint32_t *pb = fb + (size_t)ngen * 4;
+    SPICEY_NOUNROLL
+    for (uint32_t j = (uint32_t)tid; j < npair; j += (uint32_t)T) {
+      uint32_t w[8];
+      for (int i = 0; i < 8; i++) w[i] = pb[(size_t)j * 8 + i];
+      spicey_exec_row16<K>(c, w, reuse);
+    }
+    base = fb;
+    sc = reuse ? P.fus_rhs[p] : ngen;
+  }
   if (sc) {
     // streamed phase (did not fit the resident slots): double-buffered — the next record's L2 fetch is in flight
     // while the current task executes.  (Fetching 4 records up front was measured slower: +16 live VGPRs pushed
     // the 1024-thread kernel to its 128-register cap.)
-    const uint32_t *base = P.rec16 + (size_t)Q.st_first[p] * 4;
     uint32_t j = (uint32_t)tid;
     if (j < sc) {
       const uint32_t *r = base + (size_t)j * 4;
@@ -1148,20 +1203,32 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
     if (SPICEY_UNIFORM((int)Q.st_cnt[p]) != 0) smask |= 1ull << p;
   }
   const int tail_n = Q.tail_n, tail_first = Q.tail_first;
-  const int pcr_n = K == 1 ? P.pcr_n : 0;
-  int pcr_S = 0;
-  while ((1 << pcr_S) < pcr_n) pcr_S++;
+  // (the tridiagonal top's two loop-control values ride in ONE scalar across the time loop and are unpacked inside it: every
+  // further live scalar there costs a lane of a spill VGPR, and the 128-register build has none to give)
+  int top_pack;
+  {
+    const int n0 = K == 1 ? P.pcr_n : 0;
+    int S0 = 0;
+    while ((1 << S0) < n0) S0++;
+    top_pack = n0 | (S0 << 8);
+  }
+  const int pcr_n = top_pack & 0xff;
   // with a tridiagonal top the factor phases end at its level and the backward phases resume below it
   const int u_end = pcr_n > 0 ? P.pcr_level : (tail_n > 0 ? tail_first : nL);
   const int k_begin = pcr_n > 0 ? 2 * nL - P.pcr_level : (tail_n > 0 ? tail_first + tail_n : nL);
-  const bool z_pre = K == 1 && k_begin < 2 * nL;  // Z's parameter fetch rides on the last backward phase
+  top_pack |= (K == 1 && k_begin < 2 * nL) ? 1 << 16 : 0;  // bit 16 = z_pre: Z's parameter fetch rides on the last backward phase
   // No diodes and no switches: the matrix of every step is the matrix of step 0 (dt is fixed within a run), so its
   // factors stay in W and later steps run the right-hand-side column only.  Same operands, same order: the results
   // are bit-identical to refactoring (SURVEY.md §8(d) "solve-only" rate; the reference itself never reuses).
-  const bool linear = P.nD == 0 && nS == 0 && P.nDynEnt == 0 && !R.no_reuse;
+  top_pack |= (P.nD == 0 && nS == 0 && P.nDynEnt == 0 && !R.no_reuse) ? 1 << 17 : 0;  // bit 17 = linear
+  top_pack = SPICEY_UNIFORM(top_pack);
   for (int64_t step = 0; step <= steps && code == 0; step++) {
     int iter = 0;
     for (;;) {
+      int tp = top_pack;
+      SPICEY_OPAQUE_S(tp);
+      const int pcr_n = tp & 0xff, pcr_S = (tp >> 8) & 0xff;
+      const bool z_pre = (tp >> 16) & 1, linear = (tp >> 17) & 1;
       ex.phase(SPICEY_PH_B, [&](int tid) {
         const SpiceyProg Pf = ex.fresh(P);
         const SpiceyRun Rf = ex.fresh(R);
@@ -1245,7 +1312,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
       if (tid == 0 && Rf.iters)
         for (int k = 0; k < K; k++)
           if (c.valid[k]) Rf.iters[(size_t)c.inst[k] * (size_t)(steps + 1) + (size_t)step] = iter + 1;
-      p2.z_record(tid, step, ex.template regs<Regs>(tid), z_pre);
+      p2.z_record(tid, step, ex.template regs<Regs>(tid), ((top_pack >> 16) & 1) != 0);
     });
   }
   ex.phase(SPICEY_PH_PRO, [&](int tid) {

@@ -115,7 +115,7 @@ class Handle:
 
     def __init__(self, flat: abi.FlatCircuit, device: int = 0, threads: int = 0, inst_per_wg: int = 0,
                  force_global: bool = False, profile: bool = False, interpreter: int = 0, geometry: int = 0, no_tail: bool = False, debug_empty_phases: int = 0, wgs_per_inst: int = 0,
-                 no_reuse: bool = False, csr_numbering: bool = False, front_cut: int = 0, stage_fronts: bool = False, no_pcr: bool = False):
+                 no_reuse: bool = False, csr_numbering: bool = False, front_cut: int = 0, stage_fronts: bool = False, no_pcr: bool = False, no_rows: bool = False):
         self.L = load()
         self.flat = flat
         opt = abi.SpiceyOptions()
@@ -125,7 +125,7 @@ class Handle:
         opt.geometry = int(geometry)
         opt.wgs_per_inst = int(wgs_per_inst)
         opt.front_cut = int(front_cut)
-        opt.debug = (1 if no_tail else 0) | (2 if no_reuse else 0) | (4 if csr_numbering else 0) | (8 if stage_fronts else 0) | (32 if no_pcr else 0) | (int(debug_empty_phases) << 8)
+        opt.debug = (1 if no_tail else 0) | (2 if no_reuse else 0) | (4 if csr_numbering else 0) | (8 if stage_fronts else 0) | (32 if no_pcr else 0) | (64 if no_rows else 0) | (int(debug_empty_phases) << 8)
         d = flat.desc()
         hp = C.c_void_p()
         rc = self.L.spicey_create(C.byref(d), C.byref(opt), C.byref(hp))
@@ -363,9 +363,9 @@ class HipBackend:
     """Backend interface used by spicey_amd.simulate: one handle per call (the reference API is stateless)."""
 
     def __init__(self, device: int = 0, threads: int = 0, inst_per_wg: int = 0, force_global: bool = False, interpreter: int = 0,
-                 geometry: int = 0, wgs_per_inst: int = 0, no_reuse: bool = False, front_cut: int = 0, stage_fronts: bool = False, no_pcr: bool = False):
+                 geometry: int = 0, wgs_per_inst: int = 0, no_reuse: bool = False, front_cut: int = 0, stage_fronts: bool = False, no_pcr: bool = False, no_rows: bool = False):
         self.kw = dict(device=device, threads=threads, inst_per_wg=inst_per_wg, force_global=force_global, interpreter=interpreter,
-                       geometry=geometry, wgs_per_inst=wgs_per_inst, no_reuse=no_reuse, front_cut=front_cut, stage_fronts=stage_fronts, no_pcr=no_pcr)
+                       geometry=geometry, wgs_per_inst=wgs_per_inst, no_reuse=no_reuse, front_cut=front_cut, stage_fronts=stage_fronts, no_pcr=no_pcr, no_rows=no_rows)
         self.info: Optional[dict] = None
 
     def run(self, flat: abi.FlatCircuit, steps: int, dt: float, src: np.ndarray, want_currents: bool = True,

@@ -92,7 +92,7 @@ struct SeqExec {
 };
 
 template <int K>
-void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T, bool reverse, int rmax, bool chain = false) {
+void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T, bool reverse, int rmax, bool chain = false, bool row_records = true) {
   const int ngroups = (R.n_inst + K - 1) / K;
   std::vector<double> W((size_t)P.nW * K), u((size_t)(P.nU + 1) * K), gd((size_t)(P.nGdyn + 1) * K);
   std::vector<int32_t> ison((size_t)(P.nS + 1) * K), flags(4);
@@ -111,7 +111,7 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
       spicey_tran_run<K, true>(ex, P, R, c, g);
     } else {
       HostResident hr;
-      spicey_build_resident(hp, T, rmax, hr, 24);
+      spicey_build_resident(hp, T, rmax, hr, 24, row_records);
       SpiceyResident Q = hr.bind(hr.blob.data());
       std::vector<uint32_t> tail((size_t)(hr.tail_n + 6) * 64 * 4);  // (+ the cyclic-reduction buffers of a tridiagonal top)
       c.tail = tail.data();
@@ -140,6 +140,7 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
   std::string err;
   const int front_cut = reverse >> 8;  // bits 8..: elimination-tree level from which pivots are factored as dense fronts
   // bit 4: no tridiagonal top (the 16-bit records then cover every level); interleaved instances (K > 1) never use it
+  // bit 5: streamed factor phases keep the generic records even where a row-record encoding exists
   int32_t rc = spicey_build_program(d, hp, err, true, front_cut, !(reverse & 16) && K == 1);
   if (rc != SPICEY_OK) return rc;
   SpiceyProg P = hp.bind(hp.blob.data());
@@ -191,9 +192,9 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
   if (T <= 0 || (T & 63)) return SPICEY_ERR_BAD_DESC;
   if (rmax > 16 || (rmax >= 0 && (!P.has16 || K > 2))) return SPICEY_ERR_BAD_DESC;  // v2 supports K <= 2
   switch (K) {
-    case 1: run_groups<1>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0); break;
-    case 2: run_groups<2>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0); break;
-    case 4: run_groups<4>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0); break;
+    case 1: run_groups<1>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0, !(reverse & 32)); break;
+    case 2: run_groups<2>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0, !(reverse & 32)); break;
+    case 4: run_groups<4>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0, !(reverse & 32)); break;
     default: return SPICEY_ERR_BAD_DESC;
   }
   int64_t tot = 0;
@@ -247,6 +248,17 @@ extern "C" int32_t spicey_emul_resident(const SpiceyDesc *d, int32_t T, int32_t 
   meta[0] = hp.hdr.nLevels; meta[1] = hr.tail_first; meta[2] = hr.tail_n; meta[3] = hp.hdr.has16;
   meta[4] = hp.hdr.pcr_n; meta[5] = hp.hdr.pcr_level;
   return SPICEY_OK;
+}
+
+// Row records per factor level (program.h: fus16), for structural tests.
+extern "C" int32_t spicey_emul_row_records(const SpiceyDesc *d, uint32_t *pairs /*[cap]*/, int32_t cap) {
+  HostProgram hp;
+  std::string err;
+  int32_t rc = spicey_build_program(d, hp, err);
+  if (rc != SPICEY_OK) return -rc;
+  const int nL = (int)hp.fus_pairs.size();
+  for (int l = 0; l < nL && l < cap; l++) pairs[l] = hp.fus_pairs[l];
+  return nL;
 }
 
 // AC sweep through the same phase code as the HIP kernel (spicey_amd/csrc/ac_exec.h), one (instance, frequency) at a time.

@@ -43,11 +43,12 @@ def _p(a, t):
 
 
 class EmulBackend:
-    def __init__(self, K=1, T=256, reverse=False, rmax=-1, no_reuse=False, chain=False, front_cut=0, stage_fronts=False, ac_resident=False, no_pcr=False):
+    def __init__(self, K=1, T=256, reverse=False, rmax=-1, no_reuse=False, chain=False, front_cut=0, stage_fronts=False, ac_resident=False, no_pcr=False, no_rows=False):
         """rmax < 0: v1 interpreter (sliced-ELL, 32-bit); rmax >= 0: v2 with `rmax` register-resident slots.
         no_reuse: refactor every step even when the circuit is linear."""
         self.K, self.T, self.reverse, self.rmax, self.no_reuse = K, T, reverse, rmax, no_reuse
         self.chain = chain  # v1 only: backward levels as a serial chain over half of the threads (group-mode emulation)
+        self.no_rows = no_rows  # v2: streamed factor phases keep one task per target entry (no row records)
         self.no_pcr = no_pcr  # v2: keep the task lists for the top levels even where their Schur complement is tridiagonal
         self.ac_resident = ac_resident  # AC: persistent workgroup per instance, task records and stamp parts in registers
         self.stage_fronts = stage_fronts  # dense fronts above 64 rows take the panel-staging (global workspace) path
@@ -72,7 +73,7 @@ class EmulBackend:
         rc = L.spicey_emul_run(C.byref(d), self.K, self.T, steps, dt, _p(src, C.c_double), _p(out_v, C.c_double),
                                _p(out_i, C.c_double), _p(iters, C.c_int32), _p(st["C_vprev"], C.c_double),
                                _p(st["L_iprev"], C.c_double), _p(st["D_vdprev"], C.c_double), _p(st["S_ison"], C.c_int32),
-                               (1 if self.reverse else 0) | (2 if self.no_reuse else 0) | (4 if self.chain else 0) | (8 if self.stage_fronts else 0) | (16 if self.no_pcr else 0) | (int(self.front_cut) << 8), C.byref(info), _p(err4, C.c_int32), C.byref(solves), self.rmax)
+                               (1 if self.reverse else 0) | (2 if self.no_reuse else 0) | (4 if self.chain else 0) | (8 if self.stage_fronts else 0) | (16 if self.no_pcr else 0) | (32 if self.no_rows else 0) | (int(self.front_cut) << 8), C.byref(info), _p(err4, C.c_int32), C.byref(solves), self.rmax)
         self.info = info.as_dict()
         self.solves = solves.value
         detail = f"singular at inst {err4[1]} step {err4[2]} iter {err4[3]}" if rc == abi.ERR_SINGULAR else ""
@@ -122,6 +123,15 @@ def resident_layout(flat: abi.FlatCircuit, T: int, rmax: int, max_tail: int, pcr
     rc = L.spicey_emul_resident(C.byref(d), T, rmax, max_tail, _p(res_phase, C.c_int32), _p(res_valid, C.c_uint32), _p(ph_cnt, C.c_uint32),
                                 _p(st_cnt, C.c_uint32), _p(meta, C.c_int32), 1 if pcr_top else 0)
     return rc, res_phase, res_valid, ph_cnt, st_cnt, meta
+
+
+def row_record_counts(flat: abi.FlatCircuit):
+    """Row records per factor level of the circuit's program (0 = the level has no row-record encoding)."""
+    out = np.zeros(4096, np.uint32)
+    d = flat.desc()
+    n = lib().spicey_emul_row_records(C.byref(d), _p(out, C.c_uint32), len(out))
+    assert n >= 0
+    return [int(x) for x in out[:n]]
 
 
 def bank_cost(flat: abi.FlatCircuit):

@@ -264,6 +264,26 @@ def test_tridiagonal_top_keeps_lu_accuracy_on_hard_driven_series_diodes(oracle_b
     assert worst["top"] <= 0.05 and worst["lists"] <= 0.05 and worst["ref"] <= 0.05, worst
 
 
+def test_row_records_are_bit_identical_to_the_tasks_they_stand_for(oracle_backend):
+    """Streamed factor phases of a chain run from 32-byte ROW records (a_ii, y_i and the fills of one target row from its
+    two pivots, sharing the multipliers) instead of one 16-byte record per target entry: the same products in the same
+    order, so the same bits — with and without the tridiagonal top, refactoring and reusing, forwards and backwards."""
+    for kind, n in (("diode_chain", 1000), ("rc_ladder", 700)):
+        flat, dt, steps, src = synth.chain_batch(kind, n, [1, 2], tran=".tran 1e-6 2e-5")
+        ref = oracle_backend.run(flat, steps, dt, src)
+        for T, rev, rmax, kw in ((256, False, 4, {}), (128, True, 0, {}), (256, False, 2, {"no_pcr": True}), (512, False, 2, {"no_reuse": True})):
+            rows = EmulBackend(1, T, rev, rmax, **kw).run(flat, steps, dt, src)
+            tasks = EmulBackend(1, T, rev, rmax, no_rows=True, **kw).run(flat, steps, dt, src)
+            assert rows["status"] == 0 and tasks["status"] == 0
+            assert np.array_equal(rows["out_v"], tasks["out_v"]) and np.array_equal(rows["out_i"], tasks["out_i"])
+            assert ratio(rows["out_v"], ref["out_v"]).max() <= 1.0 and ratio(rows["out_i"], ref["out_i"]).max() <= 1.0
+    # the encoding exists exactly where rows have the ladder pattern: the two widest levels of the chain, none on a mesh
+    from emul.pyemul import row_record_counts
+    pairs = row_record_counts(abi.flatten(parseNetlist(synth.diode_chain(1000))))
+    assert pairs[0] >= 400 and pairs[1] >= 200 and all(p == 0 or p >= 64 for p in pairs)
+    assert sum(row_record_counts(abi.flatten(parseNetlist(synth.rcd_mesh(12))))) == 0
+
+
 def test_algorithmic_bytes_match_survey():
     """config 2 = 216 048 B, config 3 = 240 024 B per solve (with the survey's nnz(L+U) = 3002)."""
     for gen, want in ((synth.rc_ladder, 216048), (synth.diode_chain, 240024)):
