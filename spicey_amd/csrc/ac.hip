@@ -172,7 +172,7 @@ extern "C" int32_t spicey_ac_create(const SpiceyDesc *desc, const SpiceyOptions 
   // NSE register slots of a thread
   h->Tres = std::min(h->T, 512);
   if (h->lds && P.has16 && P.nLU <= SPICEY_AC_NSE * h->Tres && (int)h->hp.ph_cnt.size() <= 254) {
-    spicey_build_resident(h->hp, h->Tres, SPICEY_AC_RMAX, h->hres, 0);
+    spicey_build_resident(h->hp, h->Tres, SPICEY_AC_RMAX, h->hres, 0, false);  // (the complex executor knows generic records only)
     if (hipMalloc(&h->d_res, h->hres.blob.size()) == hipSuccess &&
         hipMemcpy(h->d_res, h->hres.blob.data(), h->hres.blob.size(), hipMemcpyHostToDevice) == hipSuccess) {
       h->dres = h->hres.bind(h->d_res);

@@ -1355,11 +1355,17 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
   }
   if (hp.hdr.has16 && nPh <= 254) {
     // 1. which phases become resident: smallest first (they are pure latency) while chunks remain;
-    //    chunk c of the running count goes to wave c % nWaves, so a phase spreads over the waves
+    //    chunk c of the running count goes to wave c % nWaves, so a phase spreads over the waves.
+    //    A factor phase with a row-record encoding (program.h: fus16) is taken in that form: its generic remainder in
+    //    one-slot chunks, its row records in chunks that own TWO consecutive slots of a wave (head + continuation).
+    // (only where the generic form would give a thread more than one task: a level narrower than the workgroup is bound by
+    // one LDS round trip either way, and a row record issues twice the operand reads of a task)
+    auto rows_of = [&](int p) -> int { return (row_records && p < (int)hp.fus_pairs.size() && (int)hp.ph_cnt[p] > T) ? (int)hp.fus_pairs[p] : 0; };
+    auto units_of = [&](int p) -> int { return rows_of(p) > 0 ? (int)hp.fus_gen[p] + 2 * rows_of(p) : (int)hp.ph_cnt[p]; };
     std::vector<int> order(nPh);
     std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return hp.ph_cnt[a] < hp.ph_cnt[b]; });
-    struct Chunk { int phase, first, count; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return units_of(a) < units_of(b); });
+    struct Chunk { int phase, first, count, kind; };  // kind 0: generic records of rec16; 1: generic remainder of fus16; 2: row head; 3: row continuation
     std::vector<std::vector<Chunk>> per_wave(nWaves);
     std::vector<int> load(nWaves, 0);
     int next_chunk = 0;
@@ -1367,11 +1373,13 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
       const int cnt = (int)hp.ph_cnt[p];
       if (cnt == 0) continue;
       if (p >= out.tail_first && p < out.tail_first + out.tail_n) continue;  // lives in the LDS tail table
-      const int need = (cnt + 63) / 64;
+      const int nrow = rows_of(p), ngen = nrow > 0 ? (int)hp.fus_gen[p] : cnt;
+      const int cg = (ngen + 63) / 64, cr = (nrow + 63) / 64;
       bool fits = true;
       {
         std::vector<int> l2 = load;
-        for (int i = 0; i < need; i++) if (++l2[(next_chunk + i) % nWaves] > rmax) fits = false;
+        for (int i = 0; i < cg; i++) if (++l2[(next_chunk + i) % nWaves] > rmax) fits = false;
+        for (int i = 0; i < cr; i++) if ((l2[(next_chunk + cg + i) % nWaves] += 2) > rmax) fits = false;
       }
       if (!fits) {  // stays streamed
         out.st_first[p] = hp.ph_first[p];
@@ -1379,28 +1387,39 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
         out.st_rhs[p] = p < (int)hp.ph_rhs.size() ? hp.ph_rhs[p] : hp.ph_cnt[p];
         // streamed anyway: take the row records — where they keep most threads busy (a level with fewer rows than half the
         // workgroup is latency-bound on the one exposed record fetch; its generic records, several per thread, overlap theirs)
-        out.st_fus[p] = (row_records && p < (int)hp.fus_pairs.size() && 2 * (int)hp.fus_pairs[p] > T) ? 1u : 0u;
+        out.st_fus[p] = (nrow > 0 && 2 * nrow > T) ? 1u : 0u;
         out.streamed_tasks += cnt;
         continue;
       }
-      for (int i = 0; i < need; i++) {
+      for (int i = 0; i < cg; i++) {
         const int w = (next_chunk + i) % nWaves;
-        per_wave[w].push_back({p, i * 64, std::min(64, cnt - i * 64)});
+        per_wave[w].push_back({p, i * 64, std::min(64, ngen - i * 64), nrow > 0 ? 1 : 0});
         load[w]++;
       }
-      next_chunk += need;
+      for (int i = 0; i < cr; i++) {
+        const int w = (next_chunk + cg + i) % nWaves;
+        per_wave[w].push_back({p, i * 64, std::min(64, nrow - i * 64), 2});
+        per_wave[w].push_back({p, i * 64, std::min(64, nrow - i * 64), 3});
+        load[w] += 2;
+      }
+      next_chunk += cg + cr;
       out.resident_tasks += cnt;
     }
-    // 2. per wave: slots in execution (phase) order, so that the kernel walks them with a cursor
+    // 2. per wave: slots in execution (phase) order, so that the kernel walks them with a cursor (stable: a row chunk's
+    //    continuation stays right behind its head)
     for (int w = 0; w < nWaves; w++) {
       std::stable_sort(per_wave[w].begin(), per_wave[w].end(), [](const Chunk &a, const Chunk &b) { return a.phase < b.phase; });
       for (size_t slot = 0; slot < per_wave[w].size(); slot++) {
         const Chunk &ch = per_wave[w][slot];
-        out.res_phase[(size_t)w * rmax + slot] = ch.phase;
+        out.res_phase[(size_t)w * rmax + slot] = ch.kind == 3 ? 0xFE : ch.phase;  // (0xFE: never a phase, nPh <= 254)
         for (int lane = 0; lane < ch.count; lane++) {
           const size_t dst = ((size_t)slot * T + (size_t)w * 64 + lane) * 4;
-          const size_t src = ((size_t)hp.ph_first[ch.phase] + ch.first + lane) * 4;
-          for (int k = 0; k < 4; k++) out.res[dst + k] = hp.rec16[src + k];
+          size_t src;
+          const std::vector<uint32_t> *from = &hp.fus16;
+          if (ch.kind == 0) { from = &hp.rec16; src = ((size_t)hp.ph_first[ch.phase] + ch.first + lane) * 4; }
+          else if (ch.kind == 1) src = ((size_t)hp.fus_first[ch.phase] + ch.first + lane) * 4;
+          else src = ((size_t)hp.fus_first[ch.phase] + hp.fus_gen[ch.phase]) * 4 + (size_t)(ch.first + lane) * 8 + (ch.kind == 3 ? 4 : 0);
+          for (int k = 0; k < 4; k++) out.res[dst + k] = (*from)[src + k];
         }
       }
     }

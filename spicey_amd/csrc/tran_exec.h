@@ -579,25 +579,21 @@ SPICEY_HD void spicey_exec_row16(const WgCtx<K> &c, const uint32_t *w, bool rhs_
   const uint32_t l1 = w[4] >> 16, d1 = w[5] & 0xffffu, u1 = w[5] >> 16, y1 = w[6] & 0xffffu, f1 = w[6] >> 16, t1 = w[7] & 0xffffu;
   const bool two = (meta & 3u) == 2u, o0 = (meta >> 4) & 1u, o1 = (meta >> 5) & 1u;
   for (int k = 0; k < K; k++) {
+    // every operand in one LDS round trip (an unused second pivot / fill: index 0, a valid address; results masked)
     double aii = c.W[(size_t)iaa * K + k], yi = c.W[(size_t)iy * K + k];
-    {
-      const double m = -(c.W[(size_t)l0 * K + k] * c.W[(size_t)d0 * K + k]);
-      const double vy = c.W[(size_t)y0 * K + k], vu = c.W[(size_t)u0 * K + k], vf = c.W[(size_t)f0 * K + k], vt = c.W[(size_t)t0 * K + k];
-      yi = fma(m, vy, yi);
-      aii = fma(m, vu, aii);
-      if (o0 && !rhs_only) c.W[(size_t)t0 * K + k] = fma(m, vf, vt);
-    }
-    SPICEY_SCHED_FENCE;
-    {  // (unused second pivot: indices 0, valid addresses; the results are masked)
-      const double m = -(c.W[(size_t)l1 * K + k] * c.W[(size_t)d1 * K + k]);
-      const double vy = c.W[(size_t)y1 * K + k], vu = c.W[(size_t)u1 * K + k], vf = c.W[(size_t)f1 * K + k], vt = c.W[(size_t)t1 * K + k];
-      const double y2 = fma(m, vy, yi), a2 = fma(m, vu, aii);
-      yi = two ? y2 : yi;
-      aii = two ? a2 : aii;
-      if (two && o1 && !rhs_only) c.W[(size_t)t1 * K + k] = fma(m, vf, vt);
-    }
+    const double vl0 = c.W[(size_t)l0 * K + k], vd0 = c.W[(size_t)d0 * K + k], vy0 = c.W[(size_t)y0 * K + k], vu0 = c.W[(size_t)u0 * K + k];
+    const double vl1 = c.W[(size_t)l1 * K + k], vd1 = c.W[(size_t)d1 * K + k], vy1 = c.W[(size_t)y1 * K + k], vu1 = c.W[(size_t)u1 * K + k];
+    const double vf0 = c.W[(size_t)f0 * K + k], vt0 = c.W[(size_t)t0 * K + k], vf1 = c.W[(size_t)f1 * K + k], vt1 = c.W[(size_t)t1 * K + k];
+    const double m0 = -(vl0 * vd0), m1 = -(vl1 * vd1);
+    yi = fma(m0, vy0, yi);
+    aii = fma(m0, vu0, aii);
+    const double y2 = fma(m1, vy1, yi), a2 = fma(m1, vu1, aii);
+    yi = two ? y2 : yi;
+    aii = two ? a2 : aii;
     c.W[(size_t)iy * K + k] = yi;
     if (!rhs_only) {
+      if (o0) c.W[(size_t)t0 * K + k] = fma(m0, vf0, vt0);
+      if (two && o1) c.W[(size_t)t1 * K + k] = fma(m1, vf1, vt1);
       if (meta & (SPICEY_R16_RECIP << 8)) {
         if (fabs(aii) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
         aii = spicey_rcp(aii);
@@ -622,7 +618,13 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
       if (sp == p) {
         uint32_t w0 = rr.w0[s], w1 = rr.w1[s], w2 = rr.w2[s], w3 = rr.w3[s];
         SPICEY_OPAQUE(w0); SPICEY_OPAQUE(w1); SPICEY_OPAQUE(w2); SPICEY_OPAQUE(w3);
-        spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3, keep_from);
+        if (!KTASK && s + 1 < RMAX && SPICEY_UNIFORM((int)((rr.phv[(s + 1) >> 2] >> (((s + 1) & 3) * 8)) & 0xffu)) == 0xFE) {  // a chunk of row records: this slot + its continuation
+          uint32_t w[8] = {w0, w1, w2, w3, rr.w0[s + 1 < RMAX ? s + 1 : s], rr.w1[s + 1 < RMAX ? s + 1 : s], rr.w2[s + 1 < RMAX ? s + 1 : s], rr.w3[s + 1 < RMAX ? s + 1 : s]};
+          SPICEY_OPAQUE(w[4]); SPICEY_OPAQUE(w[5]); SPICEY_OPAQUE(w[6]); SPICEY_OPAQUE(w[7]);
+          spicey_exec_row16<K>(c, w, reuse);
+        } else {
+          spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3, keep_from);
+        }
       }
     }
   } else {
@@ -635,8 +637,15 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
       if (sp != p) break;
       uint32_t w0 = rr.w0[q], w1 = rr.w1[q], w2 = rr.w2[q], w3 = rr.w3[q];
       SPICEY_OPAQUE(w0); SPICEY_OPAQUE(w1); SPICEY_OPAQUE(w2); SPICEY_OPAQUE(w3);
-      spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3, keep_from);
-      q++;
+      if (!KTASK && q + 1 < RMAX && SPICEY_UNIFORM((int)((rr.phv[(q + 1) >> 2] >> (((q + 1) & 3) * 8)) & 0xffu)) == 0xFE) {  // a chunk of row records: this slot + its continuation
+        uint32_t w[8] = {w0, w1, w2, w3, rr.w0[q + 1], rr.w1[q + 1], rr.w2[q + 1], rr.w3[q + 1]};
+        SPICEY_OPAQUE(w[4]); SPICEY_OPAQUE(w[5]); SPICEY_OPAQUE(w[6]); SPICEY_OPAQUE(w[7]);
+        spicey_exec_row16<K>(c, w, reuse);
+        q += 2;
+      } else {
+        spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3, keep_from);
+        q++;
+      }
     }
     rr.cursor = q;
   }

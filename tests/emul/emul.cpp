@@ -233,13 +233,13 @@ extern "C" int32_t spicey_emul_symbolic(const SpiceyDesc *d, int32_t *cpos, int3
 extern "C" int32_t spicey_emul_resident(const SpiceyDesc *d, int32_t T, int32_t rmax, int32_t max_tail, int32_t *res_phase /*[T/64][rmax]*/,
                                         uint32_t *res_valid /*[rmax][T] 1 if the slot holds a task*/, uint32_t *ph_cnt /*[2L]*/,
                                         uint32_t *st_cnt /*[2L]*/, int32_t *meta /*[6]: nLevels, tail_first, tail_n, has16, pcr_n, pcr_level*/,
-                                        int32_t pcr_top) {
+                                        int32_t pcr_top /* bit 0: tridiagonal top; bit 1: row records */) {
   HostProgram hp;
   std::string err;
-  int32_t rc = spicey_build_program(d, hp, err, true, 0, pcr_top != 0);
+  int32_t rc = spicey_build_program(d, hp, err, true, 0, (pcr_top & 1) != 0);
   if (rc != SPICEY_OK) return rc;
   HostResident hr;
-  spicey_build_resident(hp, T, rmax, hr, max_tail);
+  spicey_build_resident(hp, T, rmax, hr, max_tail, (pcr_top & 2) != 0);
   const int nPh = (int)hp.ph_cnt.size();
   memcpy(res_phase, hr.res_phase.data(), sizeof(int32_t) * hr.res_phase.size());
   for (int s = 0; s < rmax; s++)
@@ -294,7 +294,7 @@ extern "C" int32_t spicey_emul_ac(const SpiceyDesc *d, int32_t T, int64_t n_freq
     // capacities (8 record slots, 2 entries per thread) so that the streamed / beyond-capacity paths run too
     if (!P.has16) return SPICEY_ERR_BAD_DESC;
     HostResident hr;
-    spicey_build_resident(hp, T, 8, hr, 0);
+    spicey_build_resident(hp, T, 8, hr, 0, false);
     SpiceyResident Q = hr.bind(hr.blob.data());
     for (int in = 0; in < d->n_inst; in++)
       for (int64_t f0 = 0; f0 < 3 && f0 < n_freq; f0++) {

@@ -110,7 +110,7 @@ def symbolic(flat: abi.FlatCircuit):
     return rc, cpos, rpos, level, info.as_dict(), prods
 
 
-def resident_layout(flat: abi.FlatCircuit, T: int, rmax: int, max_tail: int, pcr_top: bool = False):
+def resident_layout(flat: abi.FlatCircuit, T: int, rmax: int, max_tail: int, pcr_top: bool = False, row_records: bool = False):
     L = lib()
     d = flat.desc()
     rc, _, _, level, info, _ = symbolic(flat)
@@ -121,7 +121,7 @@ def resident_layout(flat: abi.FlatCircuit, T: int, rmax: int, max_tail: int, pcr
     st_cnt = np.zeros(nph, np.uint32)
     meta = np.zeros(6, np.int32)
     rc = L.spicey_emul_resident(C.byref(d), T, rmax, max_tail, _p(res_phase, C.c_int32), _p(res_valid, C.c_uint32), _p(ph_cnt, C.c_uint32),
-                                _p(st_cnt, C.c_uint32), _p(meta, C.c_int32), 1 if pcr_top else 0)
+                                _p(st_cnt, C.c_uint32), _p(meta, C.c_int32), (1 if pcr_top else 0) | (2 if row_records else 0))
     return rc, res_phase, res_valid, ph_cnt, st_cnt, meta
 
 

@@ -277,6 +277,15 @@ def test_row_records_are_bit_identical_to_the_tasks_they_stand_for(oracle_backen
             assert rows["status"] == 0 and tasks["status"] == 0
             assert np.array_equal(rows["out_v"], tasks["out_v"]) and np.array_equal(rows["out_i"], tasks["out_i"])
             assert ratio(rows["out_v"], ref["out_v"]).max() <= 1.0 and ratio(rows["out_i"], ref["out_i"]).max() <= 1.0
+    # resident layout: a chunk of row records owns two consecutive slots of its wave (head + continuation 0xFE), and with
+    # them the 1024-thread geometry holds the whole program in fewer slots
+    from emul.pyemul import resident_layout
+    _, ph_rows, _, _, st_rows, _ = resident_layout(abi.flatten(parseNetlist(synth.diode_chain(1000))), 1024, 8, 24, pcr_top=True, row_records=True)
+    assert st_rows.sum() == 0 and (ph_rows == 0xFE).sum() >= 8
+    for w in range(ph_rows.shape[0]):
+        for sl in range(ph_rows.shape[1]):
+            if ph_rows[w, sl] == 0xFE:
+                assert sl > 0 and 0 <= ph_rows[w, sl - 1] < 11 and (sl + 1 == ph_rows.shape[1] or ph_rows[w, sl + 1] != 0xFE)
     # the encoding exists exactly where rows have the ladder pattern: the two widest levels of the chain, none on a mesh
     from emul.pyemul import row_record_counts
     pairs = row_record_counts(abi.flatten(parseNetlist(synth.diode_chain(1000))))

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--no-tail", type=int, default=0)
     ap.add_argument("--empty", type=int, default=0)
     ap.add_argument("--packed", type=int, default=0)
+    ap.add_argument("--no-rows", type=int, default=0, help="1: wide factor levels keep one task per target entry (A/B against the row records)")
+    ap.add_argument("--no-pcr", type=int, default=0, help="1: no tridiagonal top")
     ap.add_argument("--csr", type=int, default=0, help="1: plain CSR numbering of the L+U entries (A/B against the bank-aware one)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -39,7 +41,7 @@ def main():
         ckt = parseNetlist(getattr(synth, args.workload)(args.n, seed=1, tran=".tran 1e-6 1e-2"))
         steps = args.steps
         src = torch.tensor(abi.source_table(ckt, 1e-6, steps), device=dev)
-        h = Handle(flat, threads=T, inst_per_wg=K, force_global=bool(args.force_global), profile=bool(args.profile), interpreter=args.interp, no_tail=bool(args.no_tail), debug_empty_phases=args.empty, geometry=2 if args.packed else 0, csr_numbering=bool(args.csr))
+        h = Handle(flat, threads=T, inst_per_wg=K, force_global=bool(args.force_global), profile=bool(args.profile), interpreter=args.interp, no_tail=bool(args.no_tail), debug_empty_phases=args.empty, geometry=2 if args.packed else 0, csr_numbering=bool(args.csr), no_rows=bool(args.no_rows), no_pcr=bool(args.no_pcr))
         info = h.info()
         out_v = torch.empty((B, steps + 1, info["n_out"]), dtype=torch.float64, device=dev)
         out_i = torch.empty((B, steps + 1, info["n_cur"]), dtype=torch.float64, device=dev) if args.currents else None
