@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -64,6 +65,31 @@ struct SpiceyHandle {
 };
 
 static thread_local std::string g_err;  // message of the calling thread's last failed spicey_create (no handle to hang it on)
+
+// roctx ranges around the host-side phases (SURVEY §5 tracing hook): `rocprofv3 --marker-trace` shows symbolic phase, uploads,
+// kernel and result copies as named ranges.  The marker library is looked up at run time (no link dependency: without it,
+// or outside a profiler, the ranges cost one null check).
+namespace {
+struct Roctx {
+  typedef int (*push_t)(const char *);
+  typedef int (*pop_t)();
+  static push_t push_fn() {
+    static push_t f = []() -> push_t {
+      for (const char *lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"})
+        if (void *hnd = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL))
+          if (void *sym = dlsym(hnd, "roctxRangePushA")) { pop_fn_ref() = (pop_t)dlsym(hnd, "roctxRangePop"); return (push_t)sym; }
+      return nullptr;
+    }();
+    return f;
+  }
+  static pop_t &pop_fn_ref() { static pop_t p = nullptr; return p; }
+  bool on;
+  explicit Roctx(const char *name) : on(false) {
+    if (push_t f = push_fn()) { f(name); on = pop_fn_ref() != nullptr; }
+  }
+  ~Roctx() { if (on) pop_fn_ref()(); }
+};
+}  // namespace
 
 #define HIPCHK(h, call)                                                                 \
   do {                                                                                  \
@@ -133,6 +159,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   SpiceyHandle *h = new SpiceyHandle();
   if (opt) h->opt = *opt;
   std::string err;
+  Roctx range_create("spicey_create");
   // dense fronts: explicit level, or automatic for large nonlinear circuits that run one instance per workgroup (the
   // interleaved K > 1 layouts and forced interpreter 2 keep the task lists); -1 = never
   int front_cut = h->opt.front_cut > 0 ? h->opt.front_cut : (h->opt.front_cut == 0 ? -1 : 0);
@@ -452,6 +479,7 @@ extern "C" int32_t spicey_run(SpiceyHandle *h, int64_t steps, double dt, const d
     return SPICEY_ERR_SINGULAR;
   }
   HIPCHK(h, hipSetDevice(h->device));
+  Roctx range_run("spicey_run");
   const SpiceyProg &P = h->hp.hdr;
   const size_t np = (size_t)steps + 1, ni = (size_t)h->n_inst;
   double *d_src = nullptr, *d_v = nullptr, *d_i = nullptr;
@@ -477,9 +505,13 @@ extern "C" int32_t spicey_run(SpiceyHandle *h, int64_t steps, double dt, const d
   TRY(hipMalloc((void **)&d_v, std::max<size_t>(ni * np * P.nOut, 1) * sizeof(double)));
   if (out_i) TRY(hipMalloc((void **)&d_i, std::max<size_t>(ni * np * P.nCur, 1) * sizeof(double)));
   if (iters) TRY(hipMalloc((void **)&d_it, ni * np * sizeof(int32_t)));
-  rc = spicey_run_device(h, steps, dt, d_src, d_v, d_i, d_it, h->stream);
-  if (rc == SPICEY_OK) rc = spicey_sync(h);
+  {
+    Roctx range_kernel("spicey_run:kernel");
+    rc = spicey_run_device(h, steps, dt, d_src, d_v, d_i, d_it, h->stream);
+    if (rc == SPICEY_OK) rc = spicey_sync(h);
+  }
   if (rc == SPICEY_OK) {
+    Roctx range_copy("spicey_run:results");
     TRY(hipMemcpy(out_v, d_v, ni * np * P.nOut * sizeof(double), hipMemcpyDeviceToHost));
     if (out_i) TRY(hipMemcpy(out_i, d_i, ni * np * P.nCur * sizeof(double), hipMemcpyDeviceToHost));
     if (iters) TRY(hipMemcpy(iters, d_it, ni * np * sizeof(int32_t), hipMemcpyDeviceToHost));
