@@ -303,6 +303,7 @@ __global__ void __launch_bounds__(FRONTS ? 512 : 1024) spicey_tran_kernel_grp(Sp
 template <class Regs>
 struct GpuExecV2 {
   unsigned long long *prof;  // LDS accumulators [SPICEY_PH_SLOTS] when profiling, else null
+  long long t_last = 0;      // profiling: end of the previous phase (slot 7 accumulates the time BETWEEN phases)
   Regs rr;
   __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
   // the argument structs live in global memory; a phase sees them through an address the compiler cannot trace back, so
@@ -335,9 +336,9 @@ struct GpuExecV2 {
   template <class F>
   __device__ __forceinline__ void wave_lockstep_keep(int nlanes, int nsteps, F f) {
     long long t0 = 0;
-    if (prof && threadIdx.x == 0) t0 = clock64();
+    if (prof && threadIdx.x == 0) { t0 = clock64(); if (t_last) atomicAdd(&prof[7], (unsigned long long)(t0 - t_last)); }
     gpu_wave_lockstep_keep(nlanes, nsteps, f);
-    if (prof && threadIdx.x == 0) atomicAdd(&prof[SPICEY_PH_U0 + 31], (unsigned long long)(clock64() - t0));
+    if (prof && threadIdx.x == 0) { t_last = clock64(); atomicAdd(&prof[SPICEY_PH_U0 + 31], (unsigned long long)(t_last - t0)); }
   }
   template <class L, class F>
   __device__ __forceinline__ void tail_phase(int tag, int nlev, L load, F f) {
@@ -362,14 +363,14 @@ struct GpuExecV2 {
   template <class F>
   __device__ __forceinline__ void phase(int tag, F f) {
     long long t0 = 0;
-    if (prof && threadIdx.x == 0) t0 = clock64();
+    if (prof && threadIdx.x == 0) { t0 = clock64(); if (t_last) atomicAdd(&prof[7], (unsigned long long)(t0 - t_last)); }
     // The thread id is made opaque per phase: otherwise hipcc hoists every `base + tid * 8` address (a VGPR
     // pair per array and instance) out of the time loop and the register-resident program spills.
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
     f(tid);
     __syncthreads();
-    if (prof && threadIdx.x == 0) atomicAdd(&prof[tag], (unsigned long long)(clock64() - t0));  // LDS: no stall
+    if (prof && threadIdx.x == 0) { t_last = clock64(); atomicAdd(&prof[tag], (unsigned long long)(t_last - t0)); }  // LDS: no stall
   }
 };
 

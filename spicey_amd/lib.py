@@ -180,7 +180,7 @@ class Handle:
         buf = (C.c_uint64 * 72)()
         self.L.spicey_debug_phase_cycles(self.h, buf, 72)
         a = list(buf)
-        return {"prologue": a[0], "B": a[1], "S": a[2], "A": a[3], "Z": a[4], "run_cycles": a[5], "run_wall_ticks_100MHz": a[6],
+        return {"prologue": a[0], "B": a[1], "S": a[2], "A": a[3], "Z": a[4], "run_cycles": a[5], "run_wall_ticks_100MHz": a[6], "between_phases": a[7],
                 "U": a[8:40], "K": a[40:72]}
 
     def section_ticks(self, wg: int) -> list:

@@ -65,7 +65,7 @@ def main():
             per = lambda v: round(v / (steps + 1))  # noqa: E731
             rec['cyc_per_step'] = dict(B=per(pc['B']), Z=per(pc['Z']), tail=per(pc['U'][31]), U=[per(x) for x in pc['U'][:info['n_levels']]],
                                        K=[per(x) for x in pc['K'][:info['n_levels']]], total=per(pc['B'] + pc['Z'] + sum(pc['U']) + sum(pc['K'])),
-                                       marks=[per(x) for x in pc['K'][16:31]], run=per(pc['run_cycles']), clock_GHz=round(pc['run_cycles'] / max(pc['run_wall_ticks_100MHz'], 1) * 0.1, 3))
+                                       gaps=per(pc['between_phases']), marks=[per(x) for x in pc['K'][16:31]], run=per(pc['run_cycles']), clock_GHz=round(pc['run_cycles'] / max(pc['run_wall_ticks_100MHz'], 1) * 0.1, 3))
         print(json.dumps(rec), flush=True)
         h.close()
         del out_v, out_i
