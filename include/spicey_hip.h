@@ -95,6 +95,8 @@ typedef struct SpiceyOptions {
                             bit 4 = AC: never use the resident sweep (one workgroup per (instance, frequency) always);
                             bit 5 = no tridiagonal top (interpreter 2 keeps its task lists for the top levels of a chain);
                             bit 6 = no row records (streamed factor levels of a chain keep one task per target entry);
+                            bit 7 = AC: no dense partial-pivoting fallback (a solve whose static pivot order hits a cancelled
+                                    diagonal reports "Complex divide by ~0" / "Singular matrix (complex)" instead);
                             bits 8.. = extra empty phases per solve */
   int32_t wgs_per_inst;  /* global-workspace path: workgroups (CUs) cooperating on one instance; 0 auto, 1 = none */
   int32_t front_cut;     /* dense fronts (large instances): pivots of elimination-tree level >= front_cut are factored as

@@ -21,6 +21,7 @@ namespace {
 
 struct GpuAcExec {
   __device__ __forceinline__ int threads() const { return (int)blockDim.x; }
+  __device__ __forceinline__ int atomic_inc(int32_t *p) { return atomicAdd(p, 1); }
   template <class F>
   __device__ __forceinline__ void phase(int, F f) {
     f((int)threadIdx.x);
@@ -64,6 +65,23 @@ __global__ void __launch_bounds__(1024) spicey_ac_kernel(SpiceyProg P, SpiceyAcR
   spicey_ac_solve(ex, P, R, W, flags, slot);
 }
 
+// Dense partial-pivoting fallback (ac_exec.h): blockIdx.x = index into the list of (instance, frequency) slots whose solve
+// tripped a pivot guard; A | b and the sparse scratch of each in global memory, reduction scratch in LDS.
+__global__ void __launch_bounds__(1024) spicey_ac_dense_kernel(const SpiceyProg *__restrict__ Pp, const SpiceyAcRun *__restrict__ Rp, const int64_t *slots,
+                                                                SpiceyCx *Ws_all, SpiceyCx *A_all) {
+  // (the two argument structs by pointer: by value their ~110 fields are all live SGPRs and some spill)
+  const SpiceyProg &P = *Pp;
+  const SpiceyAcRun &R = *Rp;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int32_t flags[2];
+  const int T = (int)blockDim.x, n = P.n;
+  double *sd = (double *)smem;
+  int32_t *si = (int32_t *)(sd + (size_t)T + 2 * (size_t)n + 2);
+  GpuAcExec ex;
+  spicey_ac_dense_solve(ex, P, R, Ws_all + (size_t)blockIdx.x * (size_t)P.nW, A_all + (size_t)blockIdx.x * (size_t)n * ((size_t)n + 1), sd, si, flags,
+                        slots[blockIdx.x]);
+}
+
 }  // namespace
 
 // resident sweep geometry: <= 512 threads (256 VGPRs, no spills): 12 task records, 10 entries' stamp parts per thread
@@ -89,6 +107,7 @@ struct SpiceyAcHandle {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0.0;
+  int64_t last_dense = 0;  // solves of the last run that went through the dense partial-pivoting fallback
   std::string err;
 };
 
@@ -213,6 +232,7 @@ extern "C" int32_t spicey_ac_get_info(SpiceyAcHandle *h, SpiceyInfo *info) {
   info->streamed_tasks = h->hres.streamed_tasks;
   info->wgs_per_inst = 1;
   info->program_bytes = (int64_t)h->hp.blob.size();
+  info->tail_levels = (int32_t)h->last_dense;  // (AC handles: solves of the last run repeated with partial pivoting)
   return SPICEY_OK;
 }
 
@@ -277,6 +297,55 @@ extern "C" int32_t spicey_ac_run(SpiceyAcHandle *h, int64_t n_freq, const double
     }
     ACCHK(h, hipEventRecord(h->ev1, h->stream));
     ACCHK(h, hipMemcpyAsync(status.data(), d_status, slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    ACCHK(h, hipStreamSynchronize(h->stream));
+    // Solves that tripped a pivot guard of the static order (a diagonal cancelling at a resonance) are repeated with
+    // partial pivoting, dense, the way the reference solves every frequency; whatever fails there fails in the reference
+    // too.  (diagnostics: SpiceyOptions.debug bit 7 = off; circuits beyond 4096 unknowns keep the error)
+    h->last_dense = 0;
+    if (!((h->opt.debug >> 7) & 1) && P.n <= 4096) {
+      std::vector<int64_t> bad;
+      for (size_t s2 = 0; s2 < slots; s2++)
+        if (status[s2] != 0) bad.push_back((int64_t)s2);
+      if (!bad.empty()) {
+        const size_t per = (size_t)P.n * ((size_t)P.n + 1) * sizeof(SpiceyCx);
+        const size_t nb = std::min(bad.size(), std::max<size_t>(1, ((size_t)1 << 30) / per));
+        int64_t *d_slots = nullptr;
+        SpiceyCx *d_A = nullptr, *d_Ws = nullptr;
+        SpiceyProg *d_P = nullptr;
+        SpiceyAcRun *d_R = nullptr;
+        auto freed = [&]() {
+          void *ps[] = {d_slots, d_A, d_Ws, d_P, d_R};
+          for (void *q : ps)
+            if (q) (void)hipFree(q);
+        };
+        if (hipMalloc((void **)&d_slots, nb * sizeof(int64_t)) != hipSuccess || hipMalloc((void **)&d_A, nb * per) != hipSuccess ||
+            hipMalloc((void **)&d_Ws, nb * (size_t)P.nW * sizeof(SpiceyCx)) != hipSuccess || hipMalloc((void **)&d_P, sizeof(SpiceyProg)) != hipSuccess ||
+            hipMalloc((void **)&d_R, sizeof(SpiceyAcRun)) != hipSuccess ||
+            hipMemcpy(d_P, &h->dprog, sizeof(SpiceyProg), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_R, &R, sizeof(SpiceyAcRun), hipMemcpyHostToDevice) != hipSuccess) {
+          freed();
+          h->err = "allocation of the dense fallback workspace failed";
+          return SPICEY_ERR_HIP;
+        }
+        const int Td = 1024;
+        const size_t lds = ((size_t)Td + 2 * (size_t)P.n + 2) * sizeof(double) + ((size_t)Td + (size_t)P.n + 4) * sizeof(int32_t);
+        hipError_t e2 = hipSuccess;
+        if (lds > 48 * 1024)
+          e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(spicey_ac_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        for (size_t b0 = 0; b0 < bad.size() && e2 == hipSuccess; b0 += nb) {
+          const size_t cnt = std::min(nb, bad.size() - b0);
+          e2 = hipMemcpyAsync(d_slots, bad.data() + b0, cnt * sizeof(int64_t), hipMemcpyHostToDevice, h->stream);
+          if (e2 != hipSuccess) break;
+          hipLaunchKernelGGL(spicey_ac_dense_kernel, dim3((unsigned)cnt), dim3(Td), lds, h->stream, d_P, d_R, d_slots, d_Ws, d_A);
+          e2 = hipGetLastError();
+          if (e2 == hipSuccess) e2 = hipStreamSynchronize(h->stream);
+        }
+        freed();
+        if (e2 != hipSuccess) { h->err = std::string("dense fallback: ") + hipGetErrorString(e2); return SPICEY_ERR_HIP; }
+        h->last_dense = (int64_t)bad.size();
+        ACCHK(h, hipMemcpyAsync(status.data(), d_status, slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+      }
+    }
     ACCHK(h, hipMemcpyAsync(out_v, d_ov, slots * (size_t)P.nOut * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (out_i) ACCHK(h, hipMemcpyAsync(out_i, d_oi, slots * (size_t)nCur * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     ACCHK(h, hipStreamSynchronize(h->stream));

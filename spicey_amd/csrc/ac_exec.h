@@ -72,7 +72,8 @@ struct AcPhases {
   }
   SPICEY_HD SpiceyCx volt(int32_t xi) const { return xi < 0 ? SpiceyCx{0.0, 0.0} : W[xi]; }
 
-  SPICEY_HD void s_stamp(int tid) const {
+  // raw: the entries as stamped (the dense fallback wants A itself, not the reciprocals of leaf diagonals)
+  SPICEY_HD void s_stamp(int tid, bool raw = false) const {
     SPICEY_NOUNROLL
     for (int e = tid; e < P.nLU; e += T) {
       SpiceyCx v{0.0, 0.0};
@@ -81,7 +82,7 @@ struct AcPhases {
         const SpiceyCx g = admittance(SPICEY_IDX(ix));
         v = (ix & SPICEY_NEG) ? cx_sub(v, g) : cx_add(v, g);
       }
-      if (P.ent_flag[e] & 1) v = pivot_inv(v);  // leaf diagonal: final as stamped
+      if (!raw && (P.ent_flag[e] & 1)) v = pivot_inv(v);  // leaf diagonal: final as stamped
       W[e] = v;
     }
     const uint32_t oV = (uint32_t)(P.nC + P.nL);
@@ -173,6 +174,139 @@ struct AcPhases {
     }
   }
 };
+
+// ---- dense fallback with partial pivoting ---------------------------------------------------------------------------------
+// The static pivot order is safe for G + jwC; with inductors a diagonal can cancel (1/(jwL) + jwC = 0 at a resonance) where
+// the reference's partial pivoting simply takes another row (solveComplex.ts:16-36).  A solve that trips the pivot guards is
+// therefore repeated here the reference's way: dense A | b in global memory in the reference's own numbering (rows = nodes
+// then branches), per column k the row of largest |A[i][k]| (first one among equals), `vmax < EPS` -> "Singular matrix
+// (complex)", a pivot with |p|^2 < EPS -> "Complex divide by ~0" (Complex.div), rows whose multiplier has |f| < EPS skipped,
+// back substitution.  One workgroup per solve; O(n^2) memory, O(n * nnz)-ish work on circuit matrices (most multipliers are
+// zero).  Exec additionally supplies atomic_inc(int *) (an LDS counter).
+// Scratch: sd[T + 2 n + 2] doubles, si[T + n + 4] ints (LDS on the GPU).
+// |z| without overflow / underflow of the squares (Math.hypot's contract; used in comparisons only)
+SPICEY_HD double cx_abs(SpiceyCx z) {
+  const double a = fabs(z.re), b = fabs(z.im);
+  const double m = a > b ? a : b, q = a > b ? b : a;
+  if (m == 0.0) return 0.0;
+  const double r = q / m;
+  return m * sqrt(1.0 + r * r);
+}
+template <class Exec>
+SPICEY_HD void spicey_ac_dense_solve(Exec &ex, const SpiceyProg &P, const SpiceyAcRun &R, SpiceyCx *Ws, SpiceyCx *A, double *sd, int32_t *si,
+                                     int32_t *flags, int64_t slot) {
+  const size_t inst = (size_t)(slot / R.n_freq);
+  const int64_t fi = slot % R.n_freq;
+  const double two_pi = 2 * 3.141592653589793;
+  const int T = ex.threads(), n = P.n;
+  const size_t ld = (size_t)n + 1;
+  AcPhases<Exec> ph{P, R, Ws, flags, T, inst, two_pi * R.freqs[fi]};
+  double *red_v = sd;                           // [T] per-thread column maxima
+  SpiceyCx *act_f = (SpiceyCx *)(sd + T);       // [n] multipliers of the rows to update
+  int32_t *red_i = si, *act_i = si + T, *scal = si + T + n;  // scal: [0] pivot row, [1] active rows
+  ex.phase(SPICEY_PH_PRO, [&](int tid) { if (tid == 0) { flags[0] = 0; scal[0] = 0; scal[1] = 0; } });
+  ex.phase(SPICEY_PH_B, [&](int tid) {
+    ph.s_stamp(tid, true);
+    for (size_t i = (size_t)tid; i < (size_t)n * ld; i += (size_t)T) A[i] = SpiceyCx{0.0, 0.0};
+  });
+  ex.phase(SPICEY_PH_B, [&](int tid) {
+    for (int e = tid; e < P.nLU; e += T) A[(size_t)P.ent_ro[e] * ld + (size_t)P.ent_co[e]] = Ws[e];
+    for (int r = tid; r < n; r += T) A[(size_t)P.pos_row[r] * ld + (size_t)n] = Ws[P.nLU + r];
+  });
+  int code = flags[0];  // (an inductor admittance the reference would refuse as well)
+  for (int k = 0; k < n && code == 0; k++) {
+    ex.phase(SPICEY_PH_U0, [&](int tid) {
+      double bv = -1.0;
+      int bi = -1;
+      for (int i = k + tid; i < n; i += T) {
+        const SpiceyCx z = A[(size_t)i * ld + (size_t)k];
+        const double v = cx_abs(z);
+        if (v > bv) { bv = v; bi = i; }
+      }
+      red_v[tid] = bv; red_i[tid] = bi;
+    });
+    ex.phase(SPICEY_PH_U0, [&](int tid) {
+      if (tid != 0) return;
+      double bv = -1.0;
+      int bi = -1;
+      const int lim = n - k < T ? n - k : T;
+      for (int t = 0; t < lim; t++)
+        if (red_v[t] > bv || (red_v[t] == bv && red_i[t] < bi)) { bv = red_v[t]; bi = red_i[t]; }
+      scal[0] = bi; scal[1] = 0;
+      if (bv < SPICEY_EPS) flags[0] = 1;
+    });
+    code = flags[0];
+    if (code) break;
+    const int imax = scal[0];
+    if (imax != k)
+      ex.phase(SPICEY_PH_U0, [&](int tid) {
+        for (int j = tid; j <= n; j += T) {
+          const SpiceyCx a = A[(size_t)k * ld + (size_t)j];
+          A[(size_t)k * ld + (size_t)j] = A[(size_t)imax * ld + (size_t)j];
+          A[(size_t)imax * ld + (size_t)j] = a;
+        }
+      });
+    ex.phase(SPICEY_PH_U0, [&](int tid) {
+      const SpiceyCx pv = A[(size_t)k * ld + (size_t)k];
+      const double d = pv.re * pv.re + pv.im * pv.im;
+      if (d < SPICEY_EPS) {  // entry.div(pivot) throws for the first row below; the last pivot is divided by on the way back
+        if (tid == 0) flags[0] = SPICEY_ERR_COMPLEX_DIV_CODE;
+        return;
+      }
+      for (int i = k + 1 + tid; i < n; i += T) {
+        const SpiceyCx en = A[(size_t)i * ld + (size_t)k];
+        const SpiceyCx f{(en.re * pv.re + en.im * pv.im) / d, (en.im * pv.re - en.re * pv.im) / d};
+        if (cx_abs(f) < SPICEY_EPS) continue;
+        const int a = ex.atomic_inc(&scal[1]);
+        act_i[a] = i; act_f[a] = f;
+      }
+    });
+    code = flags[0];
+    if (code) break;
+    const int na = scal[1];
+    if (na > 0)
+      ex.phase(SPICEY_PH_U0, [&](int tid) {
+        const int nw = T >> 6, wv = tid >> 6, lane = tid & 63;
+        for (int a = wv; a < na; a += nw) {
+          const int i = act_i[a];
+          const SpiceyCx f = act_f[a];
+          for (int j = k + lane; j <= n; j += 64) {
+            const SpiceyCx src = A[(size_t)k * ld + (size_t)j];
+            A[(size_t)i * ld + (size_t)j] = cx_sub(A[(size_t)i * ld + (size_t)j], cx_mul(f, src));
+          }
+        }
+      });
+  }
+  for (int j = n - 1; j >= 0 && code == 0; j--) {
+    ex.phase(SPICEY_PH_K0, [&](int tid) {
+      if (tid != 0) return;
+      const SpiceyCx pv = A[(size_t)j * ld + (size_t)j], s = A[(size_t)j * ld + (size_t)n];
+      const double d = pv.re * pv.re + pv.im * pv.im;
+      if (d < SPICEY_EPS) { flags[0] = SPICEY_ERR_COMPLEX_DIV_CODE; return; }
+      A[(size_t)j * ld + (size_t)n] = SpiceyCx{(s.re * pv.re + s.im * pv.im) / d, (s.im * pv.re - s.re * pv.im) / d};
+    });
+    code = flags[0];
+    if (code) break;
+    if (j > 0)
+      ex.phase(SPICEY_PH_K0, [&](int tid) {
+        const SpiceyCx xj = A[(size_t)j * ld + (size_t)n];
+        for (int i = tid; i < j; i += T) {
+          const SpiceyCx cf = A[(size_t)i * ld + (size_t)j];
+          if (cf.re == 0.0 && cf.im == 0.0) continue;
+          A[(size_t)i * ld + (size_t)n] = cx_sub(A[(size_t)i * ld + (size_t)n], cx_mul(cf, xj));
+        }
+      });
+  }
+  const int final_code = code;
+  ex.phase(SPICEY_PH_K0, [&](int tid) {
+    if (final_code == 0)
+      for (int kk = tid; kk < n; kk += T) Ws[P.nLU + kk] = A[(size_t)P.pos_col[kk] * ld + (size_t)n];
+  });
+  ex.phase(SPICEY_PH_Z, [&](int tid) {
+    if (final_code == 0) ph.z_record(tid, fi);
+    if (tid == 0) R.status[slot] = final_code;
+  });
+}
 
 // One (instance, frequency) solve by one workgroup.  All control flow is workgroup-uniform.
 template <class Exec>

@@ -155,6 +155,12 @@ struct SpiceyProg {
   const SpiceyFront *fr;
   const uint32_t *fr_asm, *fr_bnd, *fr_child, *fr_rel;
 
+  // --- natural (reference) numbering of what the workspace holds, for the AC sweep's dense partial-pivoting fallback
+  //     (ac_exec.h): entry id -> row / column of A as simulateAC.ts builds it (node - 1, branches behind the nodes);
+  //     pivot position -> natural row (right-hand side W[nLU + r]) and natural column (solution W[nLU + k])
+  const int32_t *ent_ro, *ent_co;   // [nLU]
+  const int32_t *pos_row, *pos_col; // [n]
+
   // --- elements: terminal positions in W (x' slots), -1 = ground
   const int32_t *R_a, *R_b, *C_a, *C_b, *L_a, *L_b, *S_a, *S_b, *S_cp, *S_cn, *D_a, *D_b;
   const int32_t *V_x;   // [nV] W index of the branch current

@@ -1247,6 +1247,13 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   hp.out_x.resize(nOut);
   for (int i = 0; i < nOut; i++) hp.out_x[i] = (d->n_out > 0 && d->out_nodes) ? xpos(d->out_nodes[i]) : (int32_t)(nLU + hp.cpos[i]);
 
+  // natural numbering of entries and pivot positions (AC dense fallback)
+  hp.pos_row.assign(n, 0); hp.pos_col.assign(n, 0);
+  for (int r = 0; r < n; r++) hp.pos_row[hp.rpos[r]] = r;
+  for (int c = 0; c < n; c++) hp.pos_col[hp.cpos[c]] = c;
+  hp.ent_ro.assign(nLU, 0); hp.ent_co.assign(nLU, 0);
+  for (int e = 0; e < nLU; e++) { hp.ent_ro[e] = hp.pos_row[E.row_of_id[e]]; hp.ent_co[e] = hp.pos_col[E.col_of_id[e]]; }
+
   hp.pack();
   return SPICEY_OK;
 }
@@ -1303,6 +1310,8 @@ void HostProgram::pack() {
   add_section(blob, offsets, fus16);     // 54
   add_section(blob, offsets, fus_first); add_section(blob, offsets, fus_gen);    // 55 56
   add_section(blob, offsets, fus_rhs); add_section(blob, offsets, fus_pairs);    // 57 58
+  add_section(blob, offsets, ent_ro); add_section(blob, offsets, ent_co);        // 59 60
+  add_section(blob, offsets, pos_row); add_section(blob, offsets, pos_col);      // 61 62
 }
 
 SpiceyProg HostProgram::bind(const void *base) const {
@@ -1327,6 +1336,7 @@ SpiceyProg HostProgram::bind(const void *base) const {
   p.fr_asm = u32(49); p.fr_bnd = u32(50); p.fr_child = u32(51); p.fr_rel = u32(52);
   p.pcr_tab = (const uint16_t *)(b + offsets[53]);
   p.fus16 = u32(54); p.fus_first = u32(55); p.fus_gen = u32(56); p.fus_rhs = u32(57); p.fus_pairs = u32(58);
+  p.ent_ro = i32(59); p.ent_co = i32(60); p.pos_row = i32(61); p.pos_col = i32(62);
   return p;
 }
 

@@ -33,6 +33,7 @@ struct HostProgram {
   std::vector<uint32_t> fus16, fus_first, fus_gen, fus_rhs, fus_pairs;  // row-record encoding of the factor phases (program.h)
   std::vector<uint16_t> pcr_tab;  // tridiagonal top in path order (hdr.pcr_n rows of 4 W indices), see program.h
   std::vector<uint32_t> ent_dd, dynx_ent, dynx_ptr, dynx_idx, row_desc, rowx, R_ab, C_ab, L_ab, D_ab;
+  std::vector<int32_t> ent_ro, ent_co, pos_row, pos_col;  // natural numbering of entries / pivot positions (program.h)
   std::vector<int32_t> R_a, R_b, C_a, C_b, L_a, L_b, S_a, S_b, S_cp, S_cn, D_a, D_b, V_x, out_x;
   // dense fronts above the cut (empty when hdr.nFronts == 0)
   std::vector<SpiceyFront> fronts;

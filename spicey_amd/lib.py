@@ -316,12 +316,13 @@ def to_precision6_native(x: float) -> str:
 class AcHandle:
     """spicey_ac_* of include/spicey_hip.h: AC sweep of n_inst instances of one topology."""
 
-    def __init__(self, flat: abi.FlatCircuit, device: int = 0, threads: int = 0, force_global: bool = False, no_resident: bool = False):
+    def __init__(self, flat: abi.FlatCircuit, device: int = 0, threads: int = 0, force_global: bool = False, no_resident: bool = False, no_dense: bool = False):
         self.L = load()
         self.flat = flat
         opt = abi.SpiceyOptions()
         opt.device, opt.threads, opt.force_global = int(device), int(threads), int(bool(force_global))
-        opt.debug = 16 if no_resident else 0  # bit 4: one workgroup per (instance, frequency) even for large batches
+        # bit 4: one workgroup per (instance, frequency) even for large batches; bit 7: no dense partial-pivoting fallback
+        opt.debug = (16 if no_resident else 0) | (128 if no_dense else 0)
         d = flat.desc()
         h = C.c_void_p()
         rc = self.L.spicey_ac_create(C.byref(d), C.byref(opt), C.byref(h))

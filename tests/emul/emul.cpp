@@ -21,6 +21,7 @@ struct SeqExec {
   bool reverse;
   void *rr = nullptr;  // per-thread "registers" of the v2 interpreter: std::vector<Regs>*
   int threads() const { return T; }
+  int atomic_inc(int32_t *p) { return (*p)++; }
   bool failed() const { return false; }
   // group-mode emulation: `chain` makes the backward levels run as a serial chain over the first T / 2 threads only
   // (what workgroup 0 of a two-workgroup group does on the GPU)
@@ -307,6 +308,18 @@ extern "C" int32_t spicey_emul_ac(const SpiceyDesc *d, int32_t T, int64_t n_freq
   for (size_t s = 0; s < slots; s++) {
     SeqExec ex{T, (reverse & 1) != 0};
     spicey_ac_solve(ex, P, R, W.data(), flags, (int64_t)s);
+  }
+  // solves that tripped a pivot guard are repeated with partial pivoting (bit 2 of `reverse`: off)
+  if (!(reverse & 4)) {
+    std::vector<SpiceyCx> A((size_t)P.n * ((size_t)P.n + 1));
+    std::vector<double> sd((size_t)T + 2 * (size_t)P.n + 2);
+    std::vector<int32_t> si((size_t)T + (size_t)P.n + 4);
+    for (size_t s = 0; s < slots; s++)
+      if (status[s]) {
+        SeqExec ex{T, (reverse & 1) != 0};
+        spicey_ac_dense_solve(ex, P, R, W.data(), A.data(), sd.data(), si.data(), flags, (int64_t)s);
+        if (info) info->tail_levels++;  // (diagnostic: number of dense fallback solves)
+      }
   }
   for (size_t s = 0; s < slots; s++)
     if (status[s]) return status[s] == 1 ? SPICEY_ERR_SINGULAR : SPICEY_ERR_COMPLEX_DIV;

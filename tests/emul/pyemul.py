@@ -43,11 +43,12 @@ def _p(a, t):
 
 
 class EmulBackend:
-    def __init__(self, K=1, T=256, reverse=False, rmax=-1, no_reuse=False, chain=False, front_cut=0, stage_fronts=False, ac_resident=False, no_pcr=False, no_rows=False):
+    def __init__(self, K=1, T=256, reverse=False, rmax=-1, no_reuse=False, chain=False, front_cut=0, stage_fronts=False, ac_resident=False, no_pcr=False, no_rows=False, ac_no_dense=False):
         """rmax < 0: v1 interpreter (sliced-ELL, 32-bit); rmax >= 0: v2 with `rmax` register-resident slots.
         no_reuse: refactor every step even when the circuit is linear."""
         self.K, self.T, self.reverse, self.rmax, self.no_reuse = K, T, reverse, rmax, no_reuse
         self.chain = chain  # v1 only: backward levels as a serial chain over half of the threads (group-mode emulation)
+        self.ac_no_dense = ac_no_dense  # AC: a solve that trips a pivot guard reports the error instead of taking the dense fallback
         self.no_rows = no_rows  # v2: streamed factor phases keep one task per target entry (no row records)
         self.no_pcr = no_pcr  # v2: keep the task lists for the top levels even where their Schur complement is tridiagonal
         self.ac_resident = ac_resident  # AC: persistent workgroup per instance, task records and stamp parts in registers
@@ -92,7 +93,7 @@ class EmulBackend:
         info = abi.SpiceyInfo()
         rc = L.spicey_emul_ac(C.byref(d), self.T, nf, _p(freqs, C.c_double), _p(ph.view(np.float64), C.c_double),
                               _p(out_v.view(np.float64), C.c_double), _p(out_i.view(np.float64), C.c_double) if want_currents else None,
-                              (1 if self.reverse else 0) | (2 if self.ac_resident else 0), C.byref(info))
+                              (1 if self.reverse else 0) | (2 if self.ac_resident else 0) | (4 if self.ac_no_dense else 0), C.byref(info))
         self.info = info.as_dict()
         detail = {1: "Singular matrix (complex)", 5: "Complex divide by ~0"}.get(rc, "")
         return {"status": rc, "detail": detail, "out_v": out_v, "out_i": out_i}

@@ -127,3 +127,15 @@ def series_diode_chain(seed: int, n: int) -> str:
             lines.append(f"DG{k} n{k+1} 0 DM")
     lines += [".tran 1e-6 2.5e-5", ".end", ""]
     return "\n".join(lines)
+
+
+def series_rlc_ladder(stages: int, r: float = 10.0, l: float = 1e-3, c: float = 1e-6) -> str:
+    """R - L - C stages in series: the node between L and C carries 1/(jwL) + jwC, which cancels at f0 = 1/(2 pi sqrt(LC)).
+    The reference's partial pivoting takes another row there; a static diagonal pivot order divides by ~0."""
+    lines = ["* series RLC ladder", "V1 in 0 AC 1"]
+    prev = "in"
+    for k in range(stages):
+        lines += [f"R{k} {prev} a{k} {r!r}", f"L{k} a{k} b{k} {l!r}", f"C{k} b{k} 0 {c!r}"]
+        prev = f"b{k}"
+    lines += [".ac lin 3 1000 2000", ".end", ""]
+    return "\n".join(lines)

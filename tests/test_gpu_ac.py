@@ -129,3 +129,41 @@ def test_ac_resident_sweep_on_gpu(oracle_backend):
     g3 = r3.run(fr, sac.source_phasors(ckt))
     o3 = oracle_backend.run_ac(f3, fr, sac.source_phasors(ckt))
     assert g3["status"] == 0 and r3.info()["interpreter"] == 2 and tol(g3["out_v"], o3["out_v"]) <= 1.0 and tol(g3["out_i"], o3["out_i"]) <= 1.0
+
+
+def test_ac_resonance_dense_fallback_on_gpu(oracle_backend):
+    """A series L - C node cancels at its resonance: the static pivot order hits ~0 there, the reference's partial
+    pivoting does not.  The HIP path repeats exactly those (instance, frequency) solves with dense partial pivoting
+    (`spicey_ac_dense_kernel`) and matches the reference at, next to and away from the resonance — in a batch whose other
+    instances resonate elsewhere, through both sweep kernels; with the fallback switched off the sweep fails; what is
+    singular for the reference stays singular."""
+    import math
+    from random_circuits import series_rlc_ladder
+    from spicey_amd.lib import AcHandle
+    flats = [abi.flatten(parseNetlist(series_rlc_ladder(12, l=1e-3 * (1 + 0.25 * k)))) for k in range(4)]
+    flat = abi.stack_instances(flats)
+    f0 = 1.0 / (2.0 * math.pi * math.sqrt(1e-3 * 1e-6))
+    freqs = np.array([f0 * (1.0 + d) for d in (1e-2, 1e-6, 1e-9, 1e-12, 0.0, -1e-10)] + [f0 / math.sqrt(1.25), 777.0])
+    vph = np.ones(flat.nV, np.complex128)
+    ref = oracle_backend.run_ac(flat, freqs, vph)
+    assert ref["status"] == 0
+    for kw in (dict(), dict(no_resident=True), dict(force_global=True)):
+        h = AcHandle(flat, **kw)
+        got = h.run(freqs, vph)
+        n_dense = h.info()["tail_levels"]
+        h.close()
+        assert got["status"] == 0, got["detail"]
+        assert 4 <= n_dense <= 8                       # instance 0 next to f0 (4-5 points), instance 1 at its own resonance
+        assert cratio(got["out_v"], ref["out_v"]).max() <= 1.0 and cratio(got["out_i"], ref["out_i"]).max() <= 1.0
+    h = AcHandle(flat, no_dense=True)
+    assert h.run(freqs, vph)["status"] == abi.ERR_COMPLEX_DIV
+    h.close()
+    text = "* floating tank\nV1 in 0 AC 1\nR1 in 0 1k\nL1 a 0 1\nC1 a 0 1\n.ac lin 1 1 1\n.end\n"
+    flat = abi.flatten(parseNetlist(text))
+    freqs = np.array([1.0 / (2.0 * math.pi)])
+    vph = np.ones(flat.nV, np.complex128)
+    ref = oracle_backend.run_ac(flat, freqs, vph)
+    h = AcHandle(flat)
+    got = h.run(freqs, vph)
+    h.close()
+    assert ref["status"] != 0 and got["status"] == ref["status"]

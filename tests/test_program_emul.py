@@ -426,6 +426,36 @@ def test_ac_resident_sweep_errors_and_batches(oracle_backend):
     assert got["status"] == 0 and cratio(got["out_v"], ref["out_v"]).max() <= 1.0 and cratio(got["out_i"], ref["out_i"]).max() <= 1.0
 
 
+def test_ac_resonance_takes_the_partial_pivoting_fallback(oracle_backend):
+    """At a resonance the node between a series L and C has admittance 1/(jwL) + jwC = 0: the static pivot order divides
+    by ~0 where the reference's partial pivoting takes another row.  Such a solve is repeated with dense partial pivoting
+    the reference's way: same answers as the reference at, next to and away from the resonance; without the fallback the
+    sweep fails; a circuit that is singular for the reference as well still reports the reference's error."""
+    import math
+    from random_circuits import series_rlc_ladder
+    for stages in (1, 3, 12):
+        flat = abi.flatten(parseNetlist(series_rlc_ladder(stages)))
+        f0 = 1.0 / (2.0 * math.pi * math.sqrt(1e-3 * 1e-6))
+        freqs = np.array([f0 * (1.0 + d) for d in (1e-2, 1e-6, 1e-9, 1e-12, 0.0, -1e-10)])
+        vph = np.ones((1, flat.nV), np.complex128)
+        ref = oracle_backend.run_ac(flat, freqs, vph)
+        assert ref["status"] == 0
+        for T, rev in ((64, False), (128, True)):
+            be = EmulBackend(1, T, rev)
+            got = be.run_ac(flat, freqs, vph)
+            assert got["status"] == 0 and be.info["tail_levels"] >= 3      # (the solves next to f0 went through the fallback)
+            assert cratio(got["out_v"], ref["out_v"]).max() <= 1.0 and cratio(got["out_i"], ref["out_i"]).max() <= 1.0
+        assert EmulBackend(1, 64, ac_no_dense=True).run_ac(flat, freqs, vph)["status"] == abi.ERR_COMPLEX_DIV
+    # singular for the reference too (an L - C node pair hanging on nothing else, at its resonance): the reference's error
+    text = "* floating tank\nV1 in 0 AC 1\nR1 in 0 1k\nL1 a 0 1\nC1 a 0 1\n.ac lin 1 1 1\n.end\n"
+    flat = abi.flatten(parseNetlist(text))
+    freqs = np.array([1.0 / (2.0 * math.pi)])
+    vph = np.ones((1, flat.nV), np.complex128)
+    ref = oracle_backend.run_ac(flat, freqs, vph)
+    got = EmulBackend(1, 64).run_ac(flat, freqs, vph)
+    assert ref["status"] != 0 and got["status"] == ref["status"]
+
+
 def test_ac_program_public_api_and_errors(oracle_backend):
     from spicey_amd import ac as sac
     g, ckt, flat, freqs, vph = _ac_inputs("ac_readme")
