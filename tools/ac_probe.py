@@ -31,6 +31,15 @@ for ni in args.inst:
         rec = dict(n=args.n, inst=ni, freqs=len(freqs), T=info["threads"], mode="resident sweep" if info["interpreter"] == 2 else "one workgroup per solve",
                    resident_tasks=info["resident_tasks"], streamed_tasks=info["streamed_tasks"], lds=info["lds_bytes"], nnz_lu=info["nnz_lu"], levels=info["n_levels"],
                    kernel_ms=best, solves=ni * len(freqs), solves_per_s=ni * len(freqs) / (best * 1e-3), wall_ms=wall * 1e3)
+        # roofline in the terms of SURVEY.md §8(d), complex: every matrix / factor entry is 16 bytes, 4 complex vectors of
+        # Nvar, one complex value per recorded node and element; fill-free nnz(L+U) = nnzA + 2 like the transient figure
+        nnz_a, nvar = info["nnz_a"], info["n_var"]
+        ncur = flat.nR + flat.nC + flat.nL + flat.nV
+        b_solve = 16 * (3 * nnz_a + 2 * (nnz_a + 2)) + 4 * (2 * nnz_a + 2) + 64 * nvar + 16 * (flat.n_nodes + ncur)
+        rec["roofline"] = dict(bound="hbm", algorithmic_bytes_per_solve=b_solve, achieved=b_solve * rec["solves_per_s"] / 1e9, peak=8000.0, unit="GB/s",
+                               frac=b_solve * rec["solves_per_s"] / 8e12,
+                               note="formula bytes of a streaming implementation; the sweep keeps matrix and factors of a solve in LDS: real traffic is the "
+                                    "16 B per recorded value it writes plus the program it re-reads from L2")
         if args.check and ni * len(freqs) * args.n <= 3e6 and args.n <= 300:
             from oracle.pyoracle import OracleBackend
             ref = OracleBackend().run_ac(flat, freqs, np.array([1.0 + 0j]))
