@@ -277,6 +277,11 @@ def test_row_records_are_bit_identical_to_the_tasks_they_stand_for(oracle_backen
             assert rows["status"] == 0 and tasks["status"] == 0
             assert np.array_equal(rows["out_v"], tasks["out_v"]) and np.array_equal(rows["out_i"], tasks["out_i"])
             assert ratio(rows["out_v"], ref["out_v"]).max() <= 1.0 and ratio(rows["out_i"], ref["out_i"]).max() <= 1.0
+    # two instances interleaved per workgroup (no tridiagonal top there): the row records serve both
+    flat, dt, steps, src = synth.chain_batch("diode_chain", 1000, [1, 2, 3, 4], tran=".tran 1e-6 6e-6")
+    rows = EmulBackend(2, 256, False, 8).run(flat, steps, dt, src)
+    tasks = EmulBackend(2, 256, False, 8, no_rows=True).run(flat, steps, dt, src)
+    assert rows["status"] == 0 and np.array_equal(rows["out_v"], tasks["out_v"]) and np.array_equal(rows["out_i"], tasks["out_i"])
     # resident layout: a chunk of row records owns two consecutive slots of its wave (head + continuation 0xFE), and with
     # them the 1024-thread geometry holds the whole program in fewer slots
     from emul.pyemul import resident_layout
