@@ -174,6 +174,11 @@ struct SpiceyProg {
 struct SpiceyResident {
   const uint32_t *st_rhs;  // [2L] leading right-hand-side tasks of a streamed factor phase (the only ones a reused factorisation runs)
   const uint32_t *st_fus;  // [2L] 1: this streamed factor phase runs from its row-record encoding (SpiceyProg::fus16)
+  // everything a streamed phase needs to find its records, in ONE 32-byte descriptor per phase (one scalar load instead of a
+  // chain of dependent ones in front of the first record fetch): {rows (0 | 1), first, count, rhs_count, rem_first, rem_count,
+  // rem_rhs, 0} — first / rem_first in 16-byte units of rec16 (rows = 0) or fus16 (rows = 1: `first` = the row pairs,
+  // `rem_*` = the generic remainder); *_rhs = the leading right-hand-side records a reused factorisation runs
+  const uint32_t *st_desc; // [2L][8]
   const uint32_t *res;        // [RMAX][T][4]
   const int32_t *res_phase;   // [T/64][RMAX]
   const uint32_t *st_first;   // [2 nLevels]

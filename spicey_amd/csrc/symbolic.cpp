@@ -1439,6 +1439,18 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
       out.st_rhs[p] = p < (int)hp.ph_rhs.size() ? hp.ph_rhs[p] : hp.ph_cnt[p];
     }
   }
+  // one descriptor per phase for the streamed path (program.h)
+  out.st_desc.assign((size_t)std::max(nPh, 1) * 8, 0u);
+  for (int p = 0; p < nPh; p++) {
+    uint32_t *dsc = &out.st_desc[(size_t)p * 8];
+    if (out.st_cnt[p] == 0) continue;
+    if (out.st_fus[p]) {
+      dsc[0] = 1u; dsc[1] = hp.fus_first[p] + hp.fus_gen[p]; dsc[2] = hp.fus_pairs[p]; dsc[3] = hp.fus_pairs[p];
+      dsc[4] = hp.fus_first[p]; dsc[5] = hp.fus_gen[p]; dsc[6] = hp.fus_rhs[p];
+    } else {
+      dsc[0] = 0u; dsc[1] = out.st_first[p]; dsc[2] = out.st_cnt[p]; dsc[3] = out.st_rhs[p];
+    }
+  }
   out.pack();
 }
 
@@ -1451,6 +1463,7 @@ void HostResident::pack() {
   add_section(blob, offsets, st_cnt);
   add_section(blob, offsets, st_rhs);
   add_section(blob, offsets, st_fus);
+  add_section(blob, offsets, st_desc);
 }
 
 SpiceyResident HostResident::bind(const void *base) const {
@@ -1462,6 +1475,7 @@ SpiceyResident HostResident::bind(const void *base) const {
   r.st_cnt = (const uint32_t *)(b + offsets[3]);
   r.st_rhs = (const uint32_t *)(b + offsets[4]);
   r.st_fus = (const uint32_t *)(b + offsets[5]);
+  r.st_desc = (const uint32_t *)(b + offsets[6]);
   r.rmax = rmax;
   r.T = T;
   r.tail_first = tail_first;

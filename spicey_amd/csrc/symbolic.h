@@ -68,7 +68,7 @@ void spicey_bank_cost(const HostProgram &hp, int64_t *cycles, int64_t *ideal);
 // Resident (register) layout of the compact records for a workgroup of T threads with `rmax` slots per
 // thread.  Blob sections: res[rmax][T][4] u32, res_phase[T/64][rmax] i32, st_first[2L] u32, st_cnt[2L] u32.
 struct HostResident {
-  std::vector<uint32_t> res, st_first, st_cnt, st_rhs, st_fus;
+  std::vector<uint32_t> res, st_first, st_cnt, st_rhs, st_fus, st_desc;
   std::vector<int32_t> res_phase;
   int rmax = 0, T = 0, tail_first = 0, tail_n = 0;
   int64_t resident_tasks = 0, streamed_tasks = 0;

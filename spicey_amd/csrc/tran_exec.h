@@ -650,22 +650,24 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
     rr.cursor = q;
   }
   if (!streamed) return;
-  uint32_t sc = (!KTASK && reuse) ? Q.st_rhs[p] : Q.st_cnt[p];  // right-hand-side tasks lead every factor phase
-  const uint32_t *base = P.rec16 + (size_t)Q.st_first[p] * 4;
-  if (!KTASK && sc && Q.st_fus[p]) {
+  // one 32-byte descriptor says where the phase's records are (SpiceyResident::st_desc)
+  const uint32_t *dsc = Q.st_desc + (size_t)p * 8;
+  const uint32_t d_rows = dsc[0], d_first = dsc[1], d_cnt = dsc[2], d_rhs = dsc[3], d_rfirst = dsc[4], d_rcnt = dsc[5], d_rrhs = dsc[6];
+  uint32_t sc = (!KTASK && reuse) ? d_rhs : d_cnt;  // right-hand-side tasks lead every factor phase
+  const uint32_t *base = P.rec16 + (size_t)d_first * 4;
+  if (!KTASK && sc && d_rows) {
     // the phase's row-record encoding: its 32-byte row records (one per thread on the chains this is for), then the few
     // generic records of rows that do not fit the pattern
-    const uint32_t *fb = P.fus16 + (size_t)P.fus_first[p] * 4;
-    const uint32_t ngen = P.fus_gen[p], npair = P.fus_pairs[p];
-    const uint32_t *pb = fb + (size_t)ngen * 4;
+    const uint32_t npair = d_cnt;
+    const uint32_t *pb = P.fus16 + (size_t)d_first * 4;
     SPICEY_NOUNROLL
     for (uint32_t j = (uint32_t)tid; j < npair; j += (uint32_t)T) {
       uint32_t w[8];
       for (int i = 0; i < 8; i++) w[i] = pb[(size_t)j * 8 + i];
       spicey_exec_row16<K>(c, w, reuse);
     }
-    base = fb;
-    sc = reuse ? P.fus_rhs[p] : ngen;
+    base = P.fus16 + (size_t)d_rfirst * 4;
+    sc = reuse ? d_rrhs : d_rcnt;
   }
   if (sc) {
     // streamed phase (did not fit the resident slots): double-buffered — the next record's L2 fetch is in flight
