@@ -8,13 +8,13 @@ import os
 import numpy as np
 import pytest
 
-from conftest import (GOLD, LARGE_GOLDENS, SINGULAR_GOLDENS, SMALL_GOLDENS, bits_equal, farr, fnum, golden_netlist, load_golden)
+from conftest import (GOLD, LARGE_GOLDENS, QUIRK_GOLDENS, SINGULAR_GOLDENS, SMALL_GOLDENS, bits_equal, farr, fnum, golden_netlist, load_golden)
 from spicey_amd import abi
 from spicey_amd.netlist import parseNetlist
 from spicey_amd.simulate import SingularMatrixError, formatTranResult, simulateTRAN
 
 
-@pytest.mark.parametrize("name", SMALL_GOLDENS)
+@pytest.mark.parametrize("name", SMALL_GOLDENS + QUIRK_GOLDENS)
 def test_small_goldens_bit_exact(name, oracle_backend):
     g = load_golden(name)
     ckt = parseNetlist(golden_netlist(g))

@@ -53,6 +53,29 @@ def test_program_vs_oracle(name, oracle_backend):
     assert np.array_equal(outs[0], outs[1])  # independent of thread count and order: deterministic
 
 
+def test_reference_skips_tiny_multipliers_and_the_sparse_path_cannot(oracle_backend):
+    """The one semantic difference of this path: `solveReal.ts:45` skips a row update whose multiplier
+    is below 1e-15.  In `skip_quirk` a diode between two grounded SOURCE nodes (12 V -> 5 V: pinned at its clamp, ~4.5e3 S in
+    the pivot row) pushes the multiplier of a reverse diode's floor conductance (1e-12 S) under that bar, and the
+    reference's v(c) — nanovolts — moves by up to 50 % although no current can reach c through that diode (the oracle
+    reproduces it bit for bit, test_oracle.py).  The sparse LU has another pivot sequence: its v(c) is the same with and
+    without the diode, equal to the reference's answer for the circuit WITHOUT it."""
+    fq, steps, dt, src = _inputs("skip_quirk")
+    fr, steps_r, dt_r, src_r = _inputs("skip_quirk_ref")
+    ref_q = oracle_backend.run(fq, steps, dt, src)
+    ref_r = oracle_backend.run(fr, steps_r, dt_r, src_r)
+    c = 2  # node c
+    assert np.abs(ref_q["out_v"][0, 1:, c] / ref_r["out_v"][0, 1:, c] - 1).max() > 0.02   # the reference itself: 2 % at step 1, 34 % at step 5
+    for rmax in (-1, 8):
+        got_q = EmulBackend(1, 64, False, rmax).run(fq, steps, dt, src)
+        got_r = EmulBackend(1, 64, False, rmax).run(fr, steps_r, dt_r, src_r)
+        assert got_q["status"] == 0 and got_r["status"] == 0
+        assert np.array_equal(got_q["out_v"], got_r["out_v"])                                # the diode between the sources changes nothing
+        assert ratio(got_r["out_v"], ref_r["out_v"]).max() <= 1.0                            # parity where the reference does not skip
+        assert ratio(got_q["out_v"][0, :, :2], ref_q["out_v"][0, :, :2]).max() <= 1.0        # a, b: parity
+        assert ratio(got_q["out_v"][0, 1:, c], ref_q["out_v"][0, 1:, c]).min() > 50.0        # c: the documented difference
+
+
 def test_bridge_rectifier_reference_is_ill_conditioned(oracle_backend):
     """Why bridge_rectifier gets a loose tolerance: the REFERENCE algorithm's own answer moves by
     > 1e-6 V when one diode's Is changes by 1e-15 relative (4 ulp), i.e. 1e-9 parity is undefined there."""
