@@ -169,31 +169,48 @@ struct FrontsRun {
 
   // ---- triangular solves of a panel: one thread per row of the L panel, one per column of the U panel (rhs included) ----
   SPICEY_HD void panel_trsm(double *Up, int su, double *Lp, int lpld, const double *Ld, const double *Dinv, int nL, int nU, int t) const {
+    // (the U columns start on a wave boundary behind the L rows: a wave that held both kinds ran both branches one after
+    // the other and was the phase's critical path)
+    const int nL64 = (nL + 63) & ~63;
     SPICEY_NOUNROLL
-    for (int it = t; it < nL + nU; it += T) {
+    for (int it = t; it < nL64 + nU; it += T) {
       double v[SPICEY_FB];
+      if (it >= nL && it < nL64) continue;
       if (it < nL) {
         double *row = Lp + (size_t)it * lpld;
         SPICEY_UNROLL
         for (int k = 0; k < SPICEY_FB; k++) v[k] = row[k];
         // right-looking: l_k = v_k / u_kk, then the 15 - k later entries lose l_k u_kj — independent of each other, so the
         // dependent chain is 16 steps instead of the 120 of a left-looking dot product per entry (same operations, same order per entry)
+        // (row k of the U block is fetched as a group before its multiply-adds: left to itself the compiler waits for every
+        // LDS read right in front of the one or two operations that use it — 60 exposed round trips per row instead of 16)
         SPICEY_UNROLL
         for (int k = 0; k < SPICEY_FB; k++) {
-          v[k] *= Dinv[k];
+          double uk[SPICEY_FB];
           SPICEY_UNROLL
-          for (int j = k + 1; j < SPICEY_FB; j++) v[j] = fma(-v[k], Up[(size_t)k * su + j], v[j]);
+          for (int j = k + 1; j < SPICEY_FB; j++) uk[j] = Up[(size_t)k * su + j];
+          const double dk = Dinv[k];
+          SPICEY_SCHED_FENCE;
+          v[k] *= dk;
+          SPICEY_UNROLL
+          for (int j = k + 1; j < SPICEY_FB; j++) v[j] = fma(-v[k], uk[j], v[j]);
+          SPICEY_SCHED_FENCE;
         }
         SPICEY_UNROLL
         for (int k = 0; k < SPICEY_FB; k++) row[k] = v[k];
       } else {
-        const int c = SPICEY_FB + (it - nL);
+        const int c = SPICEY_FB + (it - nL64);
         SPICEY_UNROLL
         for (int k = 0; k < SPICEY_FB; k++) v[k] = Up[(size_t)k * su + c];
         SPICEY_UNROLL
         for (int k = 0; k < SPICEY_FB - 1; k++) {
+          double lk[SPICEY_FB];
           SPICEY_UNROLL
-          for (int i2 = k + 1; i2 < SPICEY_FB; i2++) v[i2] = fma(-Ld[i2 * SPICEY_FB + k], v[k], v[i2]);
+          for (int i2 = k + 1; i2 < SPICEY_FB; i2++) lk[i2] = Ld[i2 * SPICEY_FB + k];
+          SPICEY_SCHED_FENCE;
+          SPICEY_UNROLL
+          for (int i2 = k + 1; i2 < SPICEY_FB; i2++) v[i2] = fma(-lk[i2], v[k], v[i2]);
+          SPICEY_SCHED_FENCE;
         }
         SPICEY_UNROLL
         for (int k = 1; k < SPICEY_FB; k++) Up[(size_t)k * su + c] = v[k];
