@@ -55,6 +55,10 @@ struct GpuExec {
   template <class F>
   __device__ __forceinline__ void wg_phase(F f) { phase(0, f); }
   template <class F>
+  __device__ __forceinline__ void for_each_wg(F f) { f(0, 1); }
+  template <class F>
+  __device__ __forceinline__ void phase_marked(int slot, F f) { phase(slot, f); }
+  template <class F>
   __device__ __forceinline__ void wave_lockstep(int nlanes, int nsteps, F f) { gpu_wave_lockstep(nlanes, nsteps, f); }
   __device__ __forceinline__ void front_post(unsigned int *, unsigned int) {}
   __device__ __forceinline__ void front_wait(unsigned int *, unsigned int) {}
@@ -136,6 +140,9 @@ struct GpuGroupExec {
   }
   __device__ __forceinline__ int wg() const { return wgi; }
   __device__ __forceinline__ double *lds() const { return lds_; }
+  // work that is split over the workgroups of the group without a barrier between them: f(this workgroup, G)
+  template <class F>
+  __device__ __forceinline__ void for_each_wg(F f) { f(wgi, G); }
   // a phase of THIS workgroup alone (every workgroup of the group runs its own): workgroup barrier only
   template <class F>
   __device__ __forceinline__ void wg_phase(F f) {
@@ -263,11 +270,25 @@ struct GpuGroupExec {
     __syncthreads();
     if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) bad = true;
   }
+  // thread ids of a group phase: wave v of workgroup g is wave v * G + g of the group, so that consecutive slices of a
+  // task list (sorted longest first) go to different workgroups
+  __device__ __forceinline__ int group_tid() const {
+    return ((((int)threadIdx.x >> 6) * G + wgi) << 6) | ((int)threadIdx.x & 63);
+  }
   template <class F>
   __device__ __forceinline__ void phase(int, F f) {
-    int tid = wgi * (int)blockDim.x + (int)threadIdx.x;
+    int tid = group_tid();
     asm volatile("" : "+v"(tid));
     f(tid);
+    barrier();
+  }
+  // the same with a section mark between this workgroup's share of the work and the group barrier (profiling)
+  template <class F>
+  __device__ __forceinline__ void phase_marked(int slot, F f) {
+    int tid = group_tid();
+    asm volatile("" : "+v"(tid));
+    f(tid);
+    if (prof) { __syncthreads(); mark(slot); }
     barrier();
   }
 };

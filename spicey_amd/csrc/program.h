@@ -154,6 +154,16 @@ struct SpiceyProg {
   int64_t front_ws;  // doubles per instance
   const SpiceyFront *fr;
   const uint32_t *fr_asm, *fr_bnd, *fr_child, *fr_rel;
+  //     Levels below the cut are SUBTREE-LOCAL (nBins > 0): the elimination subtrees hanging below the cut are dealt
+  //     into nBins bins of equal work; a task whose target has its smaller pivot below the cut touches only entries its
+  //     own subtree writes, so the slices of level l are stored bin by bin (bin_upd[l * (nBins + 1) + b] = first slice of
+  //     bin b at level l, [.. + nBins] = lvl_slice[l + 1]) and workgroup g of a group of G walks bins g, g + G, ... over
+  //     ALL levels below the cut with workgroup barriers only.  Targets above the cut (front entries, upper right-hand
+  //     sides) collect their products of every level below the cut, in (level, pivot) order, in the one all-workgroup
+  //     phase stored as factor level `front_cut`.  bin_bk: the same for the backward levels below the cut (targets = rows
+  //     of the bin's subtrees), after the interface phase.
+  int32_t nBins, pad_bins_;
+  const uint32_t *bin_upd, *bin_bk;  // [front_cut][nBins + 1]
 
   // --- natural (reference) numbering of what the workspace holds, for the AC sweep's dense partial-pivoting fallback
   //     (ac_exec.h): entry id -> row / column of A as simulateAC.ts builds it (node - 1, branches behind the nodes);

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <numeric>
 
 namespace {
@@ -787,6 +788,40 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   hp.hdr.front_cut = Lc;
   hp.hdr.one_slot = nLU + n;
   if (Lc > 0) hp.hdr.nW = nLU + n + 1;  // + the constant-one slot
+  // Subtree-local levels below the cut (program.h): bin_of[k] for every pivot below the cut.  The subtrees (rooted where
+  // the parent's level reaches the cut) are dealt into bins largest first, each to the lightest bin so far.
+  std::vector<int> bin_of(n, -1);
+  int nBins = 0;
+  if (Lc > 0) {
+    int want = 128;
+    if (const char *e = getenv("SPICEY_BINS")) want = atoi(e);  // experiments (0: every level below the cut is a group phase)
+    std::vector<int> sub_of(n, -1);
+    std::vector<double> sub_work;
+    for (int k = n - 1; k >= 0; k--) {  // parents are numbered behind their children
+      if (hp.level[k] >= Lc) continue;
+      const int p = hp.parent[k];
+      if (p < 0 || hp.level[p] >= Lc) { sub_of[k] = (int)sub_work.size(); sub_work.push_back(0.0); }
+      else sub_of[k] = sub_of[p];
+      const double u = (double)upper[k].size();
+      sub_work[sub_of[k]] += u * (u + 1.0) + 4.0;
+    }
+    nBins = std::min<int>(want, (int)sub_work.size());
+    if (nBins > 0) {
+      std::vector<int> order(sub_work.size());
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sub_work[a] > sub_work[b]; });
+      std::vector<double> load(nBins, 0.0);
+      std::vector<int> bin_of_sub(sub_work.size(), 0);
+      for (int sidx : order) {
+        const int b = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        bin_of_sub[sidx] = b;
+        load[b] += sub_work[sidx];
+      }
+      for (int k = 0; k < n; k++) if (sub_of[k] >= 0) bin_of[k] = bin_of_sub[sub_of[k]];
+    }
+  }
+  hp.hdr.nBins = nBins;
+  hp.bin_upd.clear(); hp.bin_bk.clear();
 
   // ---- 5a. stamp lists --------------------------------------------------------------------------
   auto ent = [&](int r_orig, int c_orig) { return E.find(hp.rpos[r_orig], hp.cpos[c_orig]); };
@@ -873,11 +908,24 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   hp.n_products = 0;
   std::vector<std::vector<int>> by_level(nLevels);
   for (int k = 0; k < n; k++) by_level[hp.level[k]].push_back(k);
+  std::map<uint32_t, std::vector<uint32_t>> iface;  // nBins > 0: products of the targets above the cut, by target
+  // the pivot that owns a factor target: the smaller index of an entry, the row of a right-hand side
+  auto owner_of = [&](uint32_t t) { return (int)t < nLU ? std::min(E.row_of_id[t], E.col_of_id[t]) : (int)t - nLU; };
   for (int l = 0; l < nLevels; l++) {
     // (target, pivot, L entry, U entry) tuples, grouped by target in pivot order
     struct Prod { uint32_t tgt, l, d, u; };
     std::vector<Prod> prods;
-    if (Lc > 0 && l >= Lc) { hp.lvl_slice.push_back((uint32_t)hp.upd_slice.size()); continue; }  // factored as dense fronts
+    if (Lc > 0 && l >= Lc) {  // factored as dense fronts
+      if (l == Lc && nBins > 0) {
+        // the targets above the cut: one task each with the products of every level below the cut, in level order
+        std::vector<std::pair<uint32_t, std::vector<uint32_t>>> tasks;
+        for (auto &kv : iface) { hp.n_products += (int64_t)kv.second.size() / 3; tasks.emplace_back(kv.first, std::move(kv.second)); }
+        iface.clear();
+        pack_slices<3>(tasks, hp.upd_slice, hp.upd_tgt, hp.upd_cnt, hp.upd_pairs);
+      }
+      hp.lvl_slice.push_back((uint32_t)hp.upd_slice.size());
+      continue;
+    }
     for (int k : by_level[l]) {
       const std::vector<int> &S = upper[k];
       for (int a : S) {
@@ -903,6 +951,26 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
       }
       tasks.emplace_back(t, std::move(flat));
       i = j;
+    }
+    if (nBins > 0) {
+      std::vector<std::vector<std::pair<uint32_t, std::vector<uint32_t>>>> per_bin(nBins);
+      for (auto &tk : tasks) {
+        const int b = bin_of[owner_of(SPICEY_IDX(tk.first))];
+        if (b < 0) {
+          std::vector<uint32_t> &dst = iface[tk.first];
+          dst.insert(dst.end(), tk.second.begin(), tk.second.end());
+        } else {
+          hp.n_products += (int64_t)tk.second.size() / 3;
+          per_bin[b].push_back(std::move(tk));
+        }
+      }
+      for (int b = 0; b < nBins; b++) {
+        hp.bin_upd.push_back((uint32_t)hp.upd_slice.size());
+        pack_slices<3>(per_bin[b], hp.upd_slice, hp.upd_tgt, hp.upd_cnt, hp.upd_pairs);
+      }
+      hp.bin_upd.push_back((uint32_t)hp.upd_slice.size());
+      hp.lvl_slice.push_back((uint32_t)hp.upd_slice.size());
+      continue;
     }
     hp.n_products += (int64_t)prods.size();
     pack_slices<3>(tasks, hp.upd_slice, hp.upd_tgt, hp.upd_cnt, hp.upd_pairs);
@@ -949,6 +1017,17 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
       i = j;
     }
     hp.n_bk_products += (int64_t)prods.size();
+    if (nBins > 0 && l < Lc) {  // rows of one bin's subtrees together (program.h)
+      std::vector<std::vector<std::pair<uint32_t, std::vector<uint32_t>>>> per_bin(nBins);
+      for (auto &tk : tasks) per_bin[bin_of[(int)tk.first - nLU]].push_back(std::move(tk));
+      for (int b = 0; b < nBins; b++) {
+        hp.bin_bk.push_back((uint32_t)hp.bk_slice.size());
+        pack_slices<3>(per_bin[b], hp.bk_slice, hp.bk_x, hp.bk_cnt, hp.bk_pairs);
+      }
+      hp.bin_bk.push_back((uint32_t)hp.bk_slice.size());
+      hp.bk_lvl_slice.push_back((uint32_t)hp.bk_slice.size());
+      continue;
+    }
     pack_slices<3>(tasks, hp.bk_slice, hp.bk_x, hp.bk_cnt, hp.bk_pairs);
     hp.bk_lvl_slice.push_back((uint32_t)hp.bk_slice.size());
   }
@@ -1312,6 +1391,7 @@ void HostProgram::pack() {
   add_section(blob, offsets, fus_rhs); add_section(blob, offsets, fus_pairs);    // 57 58
   add_section(blob, offsets, ent_ro); add_section(blob, offsets, ent_co);        // 59 60
   add_section(blob, offsets, pos_row); add_section(blob, offsets, pos_col);      // 61 62
+  add_section(blob, offsets, bin_upd); add_section(blob, offsets, bin_bk);       // 63 64
 }
 
 SpiceyProg HostProgram::bind(const void *base) const {
@@ -1337,6 +1417,7 @@ SpiceyProg HostProgram::bind(const void *base) const {
   p.pcr_tab = (const uint16_t *)(b + offsets[53]);
   p.fus16 = u32(54); p.fus_first = u32(55); p.fus_gen = u32(56); p.fus_rhs = u32(57); p.fus_pairs = u32(58);
   p.ent_ro = i32(59); p.ent_co = i32(60); p.pos_row = i32(61); p.pos_col = i32(62);
+  p.bin_upd = u32(63); p.bin_bk = u32(64);
   return p;
 }
 

@@ -38,6 +38,7 @@ struct HostProgram {
   // dense fronts above the cut (empty when hdr.nFronts == 0)
   std::vector<SpiceyFront> fronts;
   std::vector<uint32_t> fr_asm, fr_bnd, fr_child, fr_rel;
+  std::vector<uint32_t> bin_upd, bin_bk;  // subtree-local levels below the cut (program.h)
   std::vector<double> front_work;  // multiply-adds of each front's partial factorisation (for the schedule)
 
   // Serialise all arrays into one blob (16-byte aligned sections) and return a SpiceyProg whose

@@ -275,14 +275,30 @@ struct TranPhases {
   // ---- U_l: Schur updates of one elimination-tree level ----------------------------------------
   SPICEY_HD void u_level(int tid, int l, bool reuse = false) const {
     const int nw = T >> 6, w = tid >> 6, lane = tid & 63;
-    for (uint32_t s = P.lvl_slice[l] + w; s < P.lvl_slice[l + 1]; s += nw) {
+    for (uint32_t s = P.lvl_slice[l] + w; s < P.lvl_slice[l + 1]; s += nw) u_slice(s, lane, reuse);
+  }
+  // the slices of level l that belong to the bins g, g + G, ... (subtree-local levels below the front cut, program.h),
+  // dealt to this workgroup's waves in one round-robin over all of them
+  SPICEY_HD void u_bins(int tid, int l, int g, int G, bool reuse) const {
+    const uint32_t nw = (uint32_t)(T >> 6), w = (uint32_t)(tid >> 6);
+    const int lane = tid & 63;
+    const uint32_t *bs = P.bin_upd + (size_t)l * (size_t)(P.nBins + 1);
+    uint32_t i = 0;
+    for (int b = g; b < P.nBins; b += G) {
+      const uint32_t s0 = bs[b], s1 = bs[b + 1];
+      for (uint32_t s = s0 + (w + nw - i % nw) % nw; s < s1; s += nw) u_slice(s, lane, reuse);
+      i += s1 - s0;
+    }
+  }
+  SPICEY_HD void u_slice(uint32_t s, int lane, bool reuse) const {
+    {
       const uint32_t t = s * 64 + lane;
       const uint32_t tgt = P.upd_tgt[t];
-      if (tgt == SPICEY_TGT_PAD) continue;
+      if (tgt == SPICEY_TGT_PAD) return;
       const uint32_t cnt = P.upd_cnt[t];
       const uint32_t off = P.upd_slice[s].off + lane;
       const uint32_t ti = SPICEY_IDX(tgt);
-      if (reuse && ti < (uint32_t)P.nLU) continue;  // reused factorisation: right-hand-side column only
+      if (reuse && ti < (uint32_t)P.nLU) return;  // reused factorisation: right-hand-side column only
       double acc[K];
       for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)ti * K + k];
       uint32_t j = 0;
@@ -323,15 +339,47 @@ struct TranPhases {
   // ---- K_l: backward substitution, column-oriented: the pivots of level l update the rows below them --------
   SPICEY_HD void k_level(int tid, int l) const {
     const int nw = T >> 6, w = tid >> 6, lane = tid & 63;
-    for (uint32_t s = P.bk_lvl_slice[l] + w; s < P.bk_lvl_slice[l + 1]; s += nw) {
+    for (uint32_t s = P.bk_lvl_slice[l] + w; s < P.bk_lvl_slice[l + 1]; s += nw) k_slice(s, lane);
+  }
+  SPICEY_HD void k_bins(int tid, int l, int g, int G) const {  // see u_bins
+    const uint32_t nw = (uint32_t)(T >> 6), w = (uint32_t)(tid >> 6);
+    const int lane = tid & 63;
+    const uint32_t *bs = P.bin_bk + (size_t)l * (size_t)(P.nBins + 1);
+    uint32_t i = 0;
+    for (int b = g; b < P.nBins; b += G) {
+      const uint32_t s0 = bs[b], s1 = bs[b + 1];
+      for (uint32_t s = s0 + (w + nw - i % nw) % nw; s < s1; s += nw) k_slice(s, lane);
+      i += s1 - s0;
+    }
+  }
+  SPICEY_HD void k_slice(uint32_t s, int lane) const {
+    {
       const uint32_t t = s * 64 + lane;
       const uint32_t yi = P.bk_x[t];
-      if (yi == SPICEY_TGT_PAD) continue;
+      if (yi == SPICEY_TGT_PAD) return;
       const uint32_t cnt = P.bk_cnt[t];
       const uint32_t off = P.bk_slice[s].off + lane;
       double acc[K];
       for (int k = 0; k < K; k++) acc[k] = c.W[(size_t)yi * K + k];
-      for (uint32_t j = 0; j < cnt; j++) {
+      uint32_t j = 0;
+      // (as in u_slice: 4 products' indices, then their operands, in flight together; the order of the sum is unchanged)
+      if constexpr (K <= 2)  // (the 4-instance kernels have no registers to spare)
+      for (; j + 4 <= cnt; j += 4) {
+        uint32_t ki[4], di[4], ui[4];
+        for (int q = 0; q < 4; q++) {
+          ki[q] = P.bk_pairs[off + ((j + q) * 3 + 0) * 64];
+          di[q] = P.bk_pairs[off + ((j + q) * 3 + 1) * 64];
+          ui[q] = P.bk_pairs[off + ((j + q) * 3 + 2) * 64];
+        }
+        double kv[4][K], dv[4][K], uv[4][K];
+        for (int q = 0; q < 4; q++)
+          for (int k = 0; k < K; k++) {
+            kv[q][k] = c.W[(size_t)ki[q] * K + k]; dv[q][k] = c.W[(size_t)di[q] * K + k]; uv[q][k] = c.W[(size_t)ui[q] * K + k];
+          }
+        for (int q = 0; q < 4; q++)
+          for (int k = 0; k < K; k++) acc[k] = fma(-(kv[q][k] * dv[q][k]), uv[q][k], acc[k]);
+      }
+      for (; j < cnt; j++) {
         const uint32_t ki = P.bk_pairs[off + (j * 3 + 0) * 64];
         const uint32_t di = P.bk_pairs[off + (j * 3 + 1) * 64];
         const uint32_t ui = P.bk_pairs[off + (j * 3 + 2) * 64];
@@ -1375,7 +1423,21 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
         // Group mode: runs of narrow factor levels (<= 1024 tasks, one per thread: the last pivots of the top separator) also go to
         // workgroup 0 alone; a group barrier separates such a run from the next level that everybody works on.
         bool local_run = false;
-        for (int l = 0; l < P.nLevels; l++) {
+        int l_first = 0;
+        if constexpr (FRONTS) if (use_fronts && P.nBins > 0) {
+          // subtree-local levels below the cut (program.h): every workgroup walks its bins through all those levels with
+          // its own barriers; one group barrier, then the targets above the cut take their products in one phase
+          ex.for_each_wg([&](int g, int G) {
+            for (int l = 0; l < P.front_cut; l++) ex.wg_phase([&](int tid) { phl.u_bins(tid, l, g, G, linear && step > 0); });
+          });
+          ex.mark(SPICEY_PH_U0 + 18);
+          ex.sync();
+          ex.mark(SPICEY_PH_U0 + 19);
+          l_first = P.front_cut;
+        }
+        // (above a front cut the lists are empty: nothing to walk; with bins, one phase is left)
+        const int l_end = use_fronts ? P.front_cut + (P.nBins > 0 ? 1 : 0) : P.nLevels;
+        for (int l = l_first; l < l_end; l++) {
           const uint32_t nsl = P.lvl_slice[l + 1] - P.lvl_slice[l];
           if (nsl == 0) continue;
           if (ex.serial_chain() && nsl <= 16) {
@@ -1384,7 +1446,8 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
           } else {
             if (local_run) ex.sync();
             local_run = false;
-            ex.phase(SPICEY_PH_U0 + (l < 31 ? l : 31), [&](int tid) { ph.u_level(tid, l, linear && step > 0); });
+            if (l_first > 0 && l == l_first) ex.phase_marked(SPICEY_PH_U0 + 22, [&](int tid) { ph.u_level(tid, l, linear && step > 0); });
+            else ex.phase(SPICEY_PH_U0 + (l < 31 ? l : 31), [&](int tid) { ph.u_level(tid, l, linear && step > 0); });
           }
         }
         // (a trailing local run flows straight into the backward chain below, which workgroup 0 runs as well)
@@ -1410,24 +1473,42 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
         // (with dense fronts the levels that are left are the WIDE ones at the bottom of the tree — thousands of rows each,
         // the interface phase included: those go to all workgroups, one group barrier each)
         bool local_run = false;
-        for (int l = P.nLevels - 1; l >= 0; l--) {
+        int l_last = 0;
+        if (use_fronts && P.nBins > 0) l_last = P.front_cut;  // (the levels below follow, bin by bin)
+        for (int l = use_fronts ? P.front_cut : P.nLevels - 1; l >= l_last; l--) {  // (backward level `front_cut`: the interface)
           const uint32_t nsl = P.bk_lvl_slice[l + 1] - P.bk_lvl_slice[l];
           if (nsl == 0) continue;
           if (use_fronts && nsl > 16) {
             if (local_run) ex.sync();
             local_run = false;
-            ex.phase(SPICEY_PH_K0 + 31, [&](int tid) { ph.k_level(tid, l); });
+            if (l_last > 0 && l == l_last) ex.phase_marked(SPICEY_PH_U0 + 23, [&](int tid) { ph.k_level(tid, l); });
+            else ex.phase(SPICEY_PH_K0 + 31, [&](int tid) { ph.k_level(tid, l); });
             continue;
           }
           ex.local_phase([&](int tid) { phl.k_level(tid, l); });
           local_run = true;
         }
+        if constexpr (FRONTS) if (l_last > 0) {
+          if (local_run) ex.sync();
+          local_run = true;  // (one group barrier behind the bins)
+          ex.mark(SPICEY_PH_U0 + 20);
+          ex.for_each_wg([&](int g, int G) {
+            for (int l = P.front_cut - 1; l >= 0; l--) ex.wg_phase([&](int tid) { phl.k_bins(tid, l, g, G); });
+          });
+          ex.mark(SPICEY_PH_U0 + 21);
+        }
         if (local_run || !use_fronts) ex.sync();
       } else {
-        for (int l = P.nLevels - 1; l >= 0; l--) {
+        int l_last = 0;
+        if (use_fronts && P.nBins > 0) l_last = P.front_cut;
+        for (int l = use_fronts ? P.front_cut : P.nLevels - 1; l >= l_last; l--) {
           if (P.bk_lvl_slice[l] == P.bk_lvl_slice[l + 1]) continue;
           ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) { ph.k_level(tid, l); });
         }
+        if constexpr (FRONTS) if (l_last > 0)
+          ex.for_each_wg([&](int g, int G) {
+            for (int l = P.front_cut - 1; l >= 0; l--) ex.wg_phase([&](int tid) { phl.k_bins(tid, l, g, G); });
+          });
       }
       ex.phase(SPICEY_PH_K0, [&](int tid) { ph.k_scale(tid); });
       ex.mark(SPICEY_PH_K0);

@@ -30,6 +30,11 @@ struct SeqExec {
   // dense fronts: the emulator is ONE workgroup (every front in postorder, no hand-offs)
   std::vector<double> lds_buf;
   int wg() const { return 0; }
+  // work the GPU splits over a group's workgroups without a barrier in between: the emulator plays `virt_wgs` workgroups
+  // one after the other, each through ALL its phases (a dependence between two of them would change the result)
+  int virt_wgs = 1;
+  template <class F>
+  void for_each_wg(F f) { for (int g = 0; g < virt_wgs; g++) f(g, virt_wgs); }
   double *lds() { return lds_buf.data(); }
   template <class F>
   void wg_phase(F f) { local_phase(f); }
@@ -56,6 +61,8 @@ struct SeqExec {
   void front_post(unsigned int *, unsigned int) {}
   void front_wait(unsigned int *, unsigned int) {}
   void mark(int) {}
+  template <class F>
+  void phase_marked(int slot, F f) { phase(slot, f); }
   template <class X>
   X fresh(const X &x) const { return x; }
   int local_threads() const { return chain ? T / 2 : T; }
@@ -93,7 +100,8 @@ struct SeqExec {
 };
 
 template <int K>
-void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T, bool reverse, int rmax, bool chain = false, bool row_records = true) {
+void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T, bool reverse, int rmax, bool chain = false, bool row_records = true,
+                int virt_wgs = 1) {
   const int ngroups = (R.n_inst + K - 1) / K;
   std::vector<double> W((size_t)P.nW * K), u((size_t)(P.nU + 1) * K), gd((size_t)(P.nGdyn + 1) * K);
   std::vector<int32_t> ison((size_t)(P.nS + 1) * K), flags(4);
@@ -107,6 +115,7 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
     }
     SeqExec ex{T, reverse};
     ex.chain = chain;
+    ex.virt_wgs = virt_wgs;
     if (P.nFronts > 0) ex.lds_buf.assign((size_t)SPICEY_FRONT_LDS_DOUBLES, 0.0);
     if (rmax < 0) {
       spicey_tran_run<K, true>(ex, P, R, c, g);
@@ -191,9 +200,12 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
     if (info) info->tail_levels = P.nFronts;  // (diagnostic: number of fronts)
   }
   if (T <= 0 || (T & 63)) return SPICEY_ERR_BAD_DESC;
+  if ((reverse & 4) && T < 128) return SPICEY_ERR_BAD_DESC;  // the chain runs on T / 2 threads: at least one wave
   if (rmax > 16 || (rmax >= 0 && (!P.has16 || K > 2))) return SPICEY_ERR_BAD_DESC;  // v2 supports K <= 2
+  // bits 6, 7: the subtree-local levels below a front cut are played as 3 / 7 (both: 21) workgroups, one after the other
+  const int virt_wgs = ((reverse & 64) ? 3 : 1) * ((reverse & 128) ? 7 : 1);
   switch (K) {
-    case 1: run_groups<1>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0, !(reverse & 32)); break;
+    case 1: run_groups<1>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0, !(reverse & 32), virt_wgs); break;
     case 2: run_groups<2>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0, !(reverse & 32)); break;
     case 4: run_groups<4>(hp, P, R, T, (reverse & 1) != 0, rmax, (reverse & 4) != 0, !(reverse & 32)); break;
     default: return SPICEY_ERR_BAD_DESC;
@@ -352,6 +364,43 @@ extern "C" int32_t spicey_emul_level_stats(const SpiceyDesc *d, int32_t cap, int
   }
   for (int k = 0; k < hp.hdr.n; k++)
     if (hp.level[k] < cap) pivots[hp.level[k]]++;
+  return SPICEY_OK;
+}
+
+// Subtree-local levels below a front cut (program.h, nBins): {bins, cut, factor slices below the cut, slices of the phase
+// that updates the targets above the cut, backward slices below the cut, widest bin's slices over all factor levels}
+extern "C" int32_t spicey_emul_bin_stats(const SpiceyDesc *d, int32_t front_cut, int32_t *out6) {
+  HostProgram hp;
+  std::string err;
+  int32_t rc = spicey_build_program(d, hp, err, true, front_cut);
+  if (rc != SPICEY_OK) return rc;
+  const int Lc = hp.hdr.front_cut, nb = hp.hdr.nBins;
+  out6[0] = nb; out6[1] = Lc;
+  out6[2] = Lc > 0 ? (int32_t)hp.lvl_slice[Lc] : 0;
+  out6[3] = Lc > 0 ? (int32_t)(hp.lvl_slice[Lc + 1] - hp.lvl_slice[Lc]) : 0;
+  out6[4] = Lc > 0 ? (int32_t)hp.bk_lvl_slice[Lc] : 0;
+  int widest = 0;
+  for (int b = 0; b < nb; b++) {
+    int sum = 0;
+    for (int l = 0; l < Lc; l++) sum += (int)(hp.bin_upd[(size_t)l * (nb + 1) + b + 1] - hp.bin_upd[(size_t)l * (nb + 1) + b]);
+    widest = std::max(widest, sum);
+  }
+  out6[5] = widest;
+  if (getenv("SPICEY_BIN_HIST") && Lc > 0) {
+    for (int pass = 0; pass < 2; pass++) {
+      const std::vector<uint32_t> &ls = pass ? hp.bk_lvl_slice : hp.lvl_slice;
+      const std::vector<SpiceySlice> &sl = pass ? hp.bk_slice : hp.upd_slice;
+      const std::vector<uint32_t> &cn = pass ? hp.bk_cnt : hp.upd_cnt;
+      long tot = 0, padded = 0; int hist[12] = {0};
+      for (uint32_t s = ls[Lc]; s < ls[Lc + 1]; s++) {
+        padded += (long)sl[s].len * 64;
+        for (int l = 0; l < 64; l++) { uint32_t c = cn[(size_t)s * 64 + l]; tot += c; int b = 0; while ((1u << b) < c && b < 11) b++; hist[b]++; }
+      }
+      fprintf(stderr, "%s interface: %u slices, %ld products (%ld padded), longest %u; log2 histogram:", pass ? "backward" : "factor", ls[Lc + 1] - ls[Lc], tot, padded, ls[Lc + 1] > ls[Lc] ? sl[ls[Lc]].len : 0);
+      for (int b = 0; b < 12; b++) fprintf(stderr, " %d", hist[b]);
+      fprintf(stderr, "\n");
+    }
+  }
   return SPICEY_OK;
 }
 

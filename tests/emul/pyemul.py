@@ -43,7 +43,7 @@ def _p(a, t):
 
 
 class EmulBackend:
-    def __init__(self, K=1, T=256, reverse=False, rmax=-1, no_reuse=False, chain=False, front_cut=0, stage_fronts=False, ac_resident=False, no_pcr=False, no_rows=False, ac_no_dense=False):
+    def __init__(self, K=1, T=256, reverse=False, rmax=-1, no_reuse=False, chain=False, front_cut=0, stage_fronts=False, ac_resident=False, no_pcr=False, no_rows=False, ac_no_dense=False, virt_wgs=1):
         """rmax < 0: v1 interpreter (sliced-ELL, 32-bit); rmax >= 0: v2 with `rmax` register-resident slots.
         no_reuse: refactor every step even when the circuit is linear."""
         self.K, self.T, self.reverse, self.rmax, self.no_reuse = K, T, reverse, rmax, no_reuse
@@ -53,6 +53,8 @@ class EmulBackend:
         self.no_pcr = no_pcr  # v2: keep the task lists for the top levels even where their Schur complement is tridiagonal
         self.ac_resident = ac_resident  # AC: persistent workgroup per instance, task records and stamp parts in registers
         self.stage_fronts = stage_fronts  # dense fronts above 64 rows take the panel-staging (global workspace) path
+        assert virt_wgs in (1, 3, 7, 21)
+        self.virt_wgs = virt_wgs  # the subtree-local levels below a front cut are played as this many workgroups, one after the other
         self.front_cut = front_cut  # v1 only: pivots of elimination-tree level >= front_cut are factored as dense fronts
         self.info = None
         self.solves = None
@@ -74,7 +76,7 @@ class EmulBackend:
         rc = L.spicey_emul_run(C.byref(d), self.K, self.T, steps, dt, _p(src, C.c_double), _p(out_v, C.c_double),
                                _p(out_i, C.c_double), _p(iters, C.c_int32), _p(st["C_vprev"], C.c_double),
                                _p(st["L_iprev"], C.c_double), _p(st["D_vdprev"], C.c_double), _p(st["S_ison"], C.c_int32),
-                               (1 if self.reverse else 0) | (2 if self.no_reuse else 0) | (4 if self.chain else 0) | (8 if self.stage_fronts else 0) | (16 if self.no_pcr else 0) | (32 if self.no_rows else 0) | (int(self.front_cut) << 8), C.byref(info), _p(err4, C.c_int32), C.byref(solves), self.rmax)
+                               (1 if self.reverse else 0) | (2 if self.no_reuse else 0) | (4 if self.chain else 0) | (8 if self.stage_fronts else 0) | (16 if self.no_pcr else 0) | (32 if self.no_rows else 0) | (64 if self.virt_wgs % 3 == 0 else 0) | (128 if self.virt_wgs % 7 == 0 else 0) | (int(self.front_cut) << 8), C.byref(info), _p(err4, C.c_int32), C.byref(solves), self.rmax)
         self.info = info.as_dict()
         self.solves = solves.value
         detail = f"singular at inst {err4[1]} step {err4[2]} iter {err4[3]}" if rc == abi.ERR_SINGULAR else ""
@@ -142,3 +144,15 @@ def bank_cost(flat: abi.FlatCircuit):
     rc = lib().spicey_emul_bank_cost(C.byref(d), _p(out, C.c_int64))
     assert rc == 0
     return (int(out[0]), int(out[1])), (int(out[2]), int(out[3]))
+
+
+def bin_stats(flat: abi.FlatCircuit, front_cut: int = -1) -> dict:
+    """Subtree-local levels below a front cut (program.h, nBins): bins, cut, slice counts."""
+    L = lib()
+    L.spicey_emul_bin_stats.restype = C.c_int32
+    L.spicey_emul_bin_stats.argtypes = [C.POINTER(abi.SpiceyDesc), C.c_int32, C.POINTER(C.c_int32)]
+    out = (C.c_int32 * 6)()
+    d = flat.desc()
+    rc = L.spicey_emul_bin_stats(C.byref(d), front_cut, out)
+    assert rc == 0, rc
+    return dict(zip(("bins", "cut", "factor_slices", "interface_slices", "backward_slices", "widest_bin_slices"), list(out)))

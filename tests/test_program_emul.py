@@ -779,6 +779,34 @@ def test_dense_fronts_vs_oracle(gen, kw, cuts, oracle_backend):
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])  # independent of thread count, order, front placement
 
 
+@pytest.mark.parametrize("gen,kw,cut", [("rcd_mesh", dict(rows=20, seed=7, tran=".tran 1e-6 5e-6"), 3),
+                                        ("rcd_mesh", dict(rows=34, seed=5, tran=".tran 1e-6 3e-6"), 6),
+                                        ("diode_chain", dict(n=300, seed=5, tran=".tran 1e-6 5e-6"), 2),
+                                        ("rc_ladder", dict(n=150, tran=".tran 1e-6 5e-6"), 2)])  # linear: the factors are reused
+def test_subtree_local_levels_below_the_cut(gen, kw, cut, monkeypatch):
+    """Below the front cut every workgroup of a group walks its own bins of elimination subtrees through all levels with
+    workgroup barriers only (program.h, nBins); the targets above the cut take their products in one phase.  Bit-identical
+    to one group phase per level (SPICEY_BINS=0), however many workgroups share the bins — each played through ALL its
+    levels before the next one starts, so a dependence between two bins would show — and in either thread order."""
+    ckt = parseNetlist(getattr(synth, gen)(**kw))
+    tr = ckt.analyses["tran"]
+    dt, steps = abi.computeEffectiveTimeStep(tr["dt"], tr["tstop"])
+    flat, src = abi.flatten(ckt), abi.source_table(ckt, dt, steps)
+    monkeypatch.setenv("SPICEY_BINS", "0")
+    base = EmulBackend(1, 128, front_cut=cut).run(flat, steps, dt, src)
+    assert base["status"] == 0
+    for bins in ("128", "5"):
+        monkeypatch.setenv("SPICEY_BINS", bins)
+        from emul.pyemul import bin_stats
+        st = bin_stats(flat, cut)
+        assert st["cut"] == cut and 0 < st["bins"] <= int(bins) and st["interface_slices"] > 0 and st["factor_slices"] > 0
+        for wgs, rev, chain in ((1, False, False), (3, True, False), (7, False, True), (21, True, True)):
+            got = EmulBackend(1, 128, rev, front_cut=cut, virt_wgs=wgs, chain=chain).run(flat, steps, dt, src)
+            assert got["status"] == 0, (bins, wgs)
+            assert np.array_equal(got["out_v"], base["out_v"]) and np.array_equal(got["out_i"], base["out_i"], equal_nan=True), (bins, wgs)
+            assert np.array_equal(got["iters"], base["iters"])
+
+
 def test_dense_fronts_random_circuits_and_errors(oracle_backend):
     """Fronts for everything above the leaves (cut 1) on the random R/C/L/V/D/S netlists, floating sources included:
     same status as the oracle (singular included), same iteration counts, parity bar."""
