@@ -156,6 +156,14 @@ struct GpuGroupExec {
   // front hand-off between two workgroups of the group: the producer's stores are drained by every wave, the workgroup
   // meets, lane 0 releases at agent scope and publishes the solve number; the consumer polls relaxed, acquires, and
   // holds its workgroup's barrier until the invalidate has completed (MI355X_MICROARCH.md, valid forms)
+  // the first workgroup whose spin runs out leaves a note for the host's error text: counter[2..7] = {kind (1 group barrier,
+  // 2 front hand-over, 3 census barrier), workgroup, barrier number / front flag index, value waited for, value seen, XCD}
+  __device__ __forceinline__ void note_timeout(unsigned int kind, unsigned int what, unsigned int want, unsigned int seen) {
+    if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u &&
+        __hip_atomic_exchange(counter + 2, kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      counter[3] = (unsigned int)wgi; counter[4] = what; counter[5] = want; counter[6] = seen; counter[7] = my_x;
+    }
+  }
   __device__ __forceinline__ void front_post(unsigned int *flag, unsigned int value) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -170,6 +178,7 @@ struct GpuGroupExec {
       unsigned int spins = 0;
       while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
         if (++spins > (1u << 22) || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          if (spins > (1u << 22)) note_timeout(2u, (unsigned int)(flag - counter), value, __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
@@ -235,6 +244,7 @@ struct GpuGroupExec {
       unsigned int spins = 0;
       while ((int)(__hip_atomic_load(hb + 272, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - hep) < 0) {
         if (++spins > (1u << 22) || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          if (spins > (1u << 22)) note_timeout(1u, hep, __hip_atomic_load(hb + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(hb + 128 + my_x * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
@@ -259,6 +269,7 @@ struct GpuGroupExec {
       unsigned int spins = 0;
       while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         if (++spins > (1u << 22) || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          if (spins > (1u << 22)) note_timeout(3u, epoch, target, __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }

@@ -458,7 +458,14 @@ extern "C" int32_t spicey_sync(SpiceyHandle *h) {
   for (int g = 0; g < h->grid; g++)
     if (status[(size_t)g * 4] != 0 && (best < 0 || status[(size_t)g * 4 + 2] < status[(size_t)best * 4 + 2])) best = g;
   if (best >= 0 && status[(size_t)best * 4] == 3) {
-    h->err = "cross-workgroup barrier timed out (group mode)";
+    // (the first workgroup that gave up left a note in its group's barrier words, GpuGroupExec::note_timeout)
+    unsigned int note[8] = {0};
+    if (h->d_gsync) (void)hipMemcpy(note, h->d_gsync + (size_t)best * SPICEY_GRP_SYNC_WORDS, sizeof(note), hipMemcpyDeviceToHost);
+    char buf[256];
+    snprintf(buf, sizeof(buf), "cross-workgroup barrier timed out (group mode) at step %d: %s, workgroup %u (XCD %u), %s %u, waited for %u, saw %u",
+             status[(size_t)best * 4 + 2], note[2] == 2 ? "front hand-over" : note[2] == 3 ? "census barrier" : "group barrier", note[3], note[7],
+             note[2] == 2 ? "flag word" : "barrier", note[4], note[5], note[6]);
+    h->err = buf;
     return SPICEY_ERR_HIP;
   }
   if (best >= 0) {
