@@ -685,6 +685,8 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   if (Lc > 0) {
     auto pad16 = [](int x) { return (x + 15) & ~15; };
     const bool relax_fronts = !getenv("SPICEY_FRONT_EXACT");  // experiments: exact supernodes only
+    int staged_mp = 176;
+    if (const char *e = getenv("SPICEY_STAGED_MERGE_MP")) staged_mp = atoi(e);  // experiments (0: off)
     for (int k = 0; k < n; k++) {
       if (hp.level[k] < Lc) continue;
       // exact nesting (upper[k-1] = {k} + upper[k]) always merges; a RELAXED merge also takes a chain pivot whose row is
@@ -698,7 +700,13 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
         const bool exact = grow == 0;
         const bool relaxed = relax_fronts && grow <= std::max<size_t>(4, upper[k].size() / 4) &&
                              pad16(pp + 1) + pad16((int)upper[k].size()) <= 128;
-        merge = exact || relaxed;
+        // A front that is staged through the workspace anyway (beyond LDS residency on its own) still merges with its
+        // chain parent while the result stays within `staged_mp` padded rows: one front's fixed cost less, and the
+        // pivots of both pad to 16 once (13 + 33 pivots: 3 panels instead of 1 + 3)
+        const bool staged = relax_fronts && staged_mp > 0 && grow <= std::max<size_t>(4, upper[k].size() / 4) &&
+                            pad16(pp) + pad16((int)upper[k - 1].size()) > 128 &&
+                            pad16(pp + 1) + pad16((int)upper[k].size()) <= staged_mp;
+        merge = exact || relaxed || staged;
       }
       if (merge) {
         front_of[k] = front_of[k - 1];

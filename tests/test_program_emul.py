@@ -807,6 +807,29 @@ def test_subtree_local_levels_below_the_cut(gen, kw, cut, monkeypatch):
             assert np.array_equal(got["iters"], base["iters"])
 
 
+def test_staged_chain_fronts_merge(monkeypatch):
+    """Fronts beyond LDS residency (> 128 padded rows: staged through the workspace panel by panel) still merge with their
+    chain parent up to 176 rows (symbolic.cpp, `staged`): fewer fronts, pivots padded to 16 once.  Same answer as without
+    the merge (a different but equally valid sum: the parity bar, not bit-identity), both with LDS-resident fronts where
+    they fit and with every large front staged."""
+    ckt = parseNetlist(synth.rcd_mesh(80, seed=4, tran=".tran 1e-6 2e-6"))
+    dt, steps = abi.computeEffectiveTimeStep(1e-6, 2e-6)
+    flat, src = abi.flatten(ckt), abi.source_table(ckt, dt, steps)
+    runs = {}
+    for mp in ("0", "176"):
+        monkeypatch.setenv("SPICEY_STAGED_MERGE_MP", mp)
+        for stage in (False, True):
+            be = EmulBackend(1, 128, stage, front_cut=10, stage_fronts=stage)
+            got = be.run(flat, steps, dt, src)
+            assert got["status"] == 0, got["detail"]
+            runs[mp, stage] = (got, be.info["tail_levels"])  # (tail_levels carries the front count here)
+    assert runs["176", False][1] < runs["0", False][1]  # the rule found chain fronts to merge
+    base = runs["0", False][0]
+    for key, (got, _) in runs.items():
+        assert ratio(got["out_v"], base["out_v"]).max() <= 1.0 and np.array_equal(got["iters"], base["iters"]), key
+    assert np.array_equal(runs["176", False][0]["out_v"], runs["176", True][0]["out_v"])  # front placement does not change the bits
+
+
 def test_dense_fronts_random_circuits_and_errors(oracle_backend):
     """Fronts for everything above the leaves (cut 1) on the random R/C/L/V/D/S netlists, floating sources included:
     same status as the oracle (singular included), same iteration counts, parity bar."""
