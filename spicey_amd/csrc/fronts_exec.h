@@ -222,19 +222,20 @@ struct FrontsRun {
   // Device: 16 x 16 tiles, four v_mfma_f64_16x16x4 each (A = -L tile, B = U tile; operand maps: lane l holds A[l & 15][l >> 4]
   // and B[l >> 4][l & 15], result register r holds C[(l >> 4) + 4 r][l & 15]); the columns up to the next multiple of 16
   // exist behind C and the U panel (zero padding, left unchanged).  Host: the plain sum, k ascending.
+  template <int NT = 4>
   SPICEY_HD void trailing(double *C, int ldc, const double *Lp, int lpld, const double *Up, int su, int nrow, int ncol, int t) const {
     const int nw = T >> 6, w = t >> 6, lane = t & 63;
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef double d4 __attribute__((ext_vector_type(4)));
     const int tr = nrow >> 4, tc = (ncol + 15) >> 4;
     const int li = lane & 15, lk = lane >> 4;
-    // four tiles per turn: their sixteen C loads are in flight together before the first MFMA needs one
-    for (int tile0 = w; tile0 < tr * tc; tile0 += 4 * nw) {
-      double *c0[4];
-      d4 acc[4];
-      bool have[4];
+    // NT tiles per turn: their 4 NT C loads are in flight together before the first MFMA needs one
+    for (int tile0 = w; tile0 < tr * tc; tile0 += NT * nw) {
+      double *c0[NT];
+      d4 acc[NT];
+      bool have[NT];
       SPICEY_UNROLL
-      for (int b = 0; b < 4; b++) {
+      for (int b = 0; b < NT; b++) {
         const int tile = tile0 + b * nw;
         have[b] = tile < tr * tc;
         const int tl = have[b] ? tile : tile0;
@@ -243,7 +244,7 @@ struct FrontsRun {
         acc[b][0] = c0[b][0]; acc[b][1] = c0[b][(size_t)4 * ldc]; acc[b][2] = c0[b][(size_t)8 * ldc]; acc[b][3] = c0[b][(size_t)12 * ldc];
       }
       SPICEY_UNROLL
-      for (int b = 0; b < 4; b++) {
+      for (int b = 0; b < NT; b++) {
         const int tile = have[b] ? tile0 + b * nw : tile0;
         const int ti = tile / tc, tj = tile - ti * tc;
         const double *la = Lp + (size_t)(ti * 16 + li) * lpld + lk;
@@ -252,7 +253,7 @@ struct FrontsRun {
         for (int kk = 0; kk < 4; kk++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[4 * kk], ub[(size_t)4 * kk * su], acc[b], 0, 0, 0);
       }
       SPICEY_UNROLL
-      for (int b = 0; b < 4; b++)
+      for (int b = 0; b < NT; b++)
         if (have[b]) { c0[b][0] = acc[b][0]; c0[b][(size_t)4 * ldc] = acc[b][1]; c0[b][(size_t)8 * ldc] = acc[b][2]; c0[b][(size_t)12 * ldc] = acc[b][3]; }
     }
 #else
@@ -325,16 +326,20 @@ struct FrontsRun {
           Lp[(size_t)r * SPICEY_LPLD + k] = A[(size_t)(j0 + SPICEY_FB + r) * F.ld + j0 + k];
         }
       });
+      ex.mark(SPICEY_PH_U0 + 24);
       diag_block(Up, su, Ld, Dinv, F.p - j0);
+      ex.mark(SPICEY_PH_U0 + 25);
       ex.wg_phase([&](int t) { panel_trsm(Up, su, Lp, SPICEY_LPLD, Ld, Dinv, nL, wU - SPICEY_FB, t); });
+      ex.mark(SPICEY_PH_U0 + 26);
       ex.wg_phase([&](int t) {
         const int nw = T >> 6, w = t >> 6, lane = t & 63;
         for (int k = w; k < SPICEY_FB; k += nw) {
           double *dst = A + (size_t)(j0 + k) * F.ld + j0;
           for (int c = lane; c < wU; c += 64) dst[c] = c == k ? Dinv[k] : Up[(size_t)k * su + c];
         }
-        trailing(A + (size_t)(j0 + SPICEY_FB) * F.ld + j0 + SPICEY_FB, F.ld, Lp, SPICEY_LPLD, Up + SPICEY_FB, su, nL, wU - SPICEY_FB, t);
+        trailing<SPICEY_TRAIL_TILES_STAGED>(A + (size_t)(j0 + SPICEY_FB) * F.ld + j0 + SPICEY_FB, F.ld, Lp, SPICEY_LPLD, Up + SPICEY_FB, su, nL, wU - SPICEY_FB, t);
       });
+      ex.mark(SPICEY_PH_U0 + 27);
     }
   }
 

@@ -4,3 +4,6 @@
 #define SPICEY_LPLD 17   // row stride (doubles) of a staged L panel in LDS: odd, so that a thread-per-row walk is bank-conflict free
 #define SPICEY_FRONT_LDS_DOUBLES 19456  // 152 KiB of LDS scratch per workgroup when a program has fronts
 #define SPICEY_FRONT_LDS_PAD 17  // an LDS-resident front has row stride Mp + 17 (odd; room for the right-hand-side tile)
+#ifndef SPICEY_TRAIL_TILES_STAGED
+#define SPICEY_TRAIL_TILES_STAGED 4  // 16 x 16 tiles a wave keeps in flight per turn of a trailing update whose C lives in the workspace (measured on rcd_mesh(100): 4 -> 0.481, 6 -> 0.486, 8 -> 0.495 ms per step)
+#endif

@@ -55,7 +55,8 @@ for rows in args.rows:
             names = {1: "B", 8: "factor<cut", 9: "fronts_fwd", 10: "fronts_bwd", 11: "publish+sync", 40: "backward", 4: "Z",
                      12: "f.wait", 13: "f.asm_children(lds)", 14: "f.factor_lds_rest", 15: "f.store", 16: "f.asm(glob)", 17: "f.factor(glob)",
                      18: "b.wait", 19: "b.solve", 20: "f.post", 21: "l.pre", 22: "l.diag", 23: "l.trsm", 24: "l.trail", 25: "a.zero+asm",
-                     26: "bins.factor", 27: "bins.sync", 28: "bk.interface", 29: "bk.bins", 30: "factor.interface.work", 31: "bk.interface.work"}
+                     26: "bins.factor", 27: "bins.sync", 28: "bk.interface", 29: "bk.bins", 30: "factor.interface.work", 31: "bk.interface.work",
+                     32: "g.stage_in", 33: "g.diag", 34: "g.trsm", 35: "g.store+trail"}
             for wgi in range(info["wgs_per_inst"]):
                 tk = h.section_ticks(wgi)
                 per = {names[k]: round(tk[k] * 10.0 / 1000.0 / (steps + 1), 1) for k in names}  # us per step
