@@ -155,8 +155,13 @@ int32_t spicey_run(SpiceyHandle *h, int64_t steps, double dt, const double *src_
  * synchronising: the error word is checked by spicey_sync(). */
 int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, const double *d_src_table,
                           double *d_out_v, double *d_out_i, int32_t *d_iters, void *stream);
-/* Wait for enqueued runs; returns SPICEY_ERR_SINGULAR etc. like spicey_run. */
+/* Wait for enqueued runs; returns SPICEY_ERR_SINGULAR etc. like spicey_run.
+ * Group mode (several workgroups per instance): every cross-workgroup wait is a bounded spin; a launch whose spin runs
+ * out aborts as a whole (nothing of it is kept) and is repeated ONCE from the state it started with, on the same stream;
+ * a second abort returns SPICEY_ERR_HIP with the first waiter's position in spicey_last_error(). */
 int32_t spicey_sync(SpiceyHandle *h);
+/* Number of launches this handle has repeated that way (0 in a healthy run; each is also reported on stderr). */
+int32_t spicey_group_retries(const SpiceyHandle *h);
 
 /* Final state after the last run (write-back to ckt: simulateTRAN.ts:221-237,122-124).
  * Any pointer may be NULL.  Arrays are [n_inst][n<kind>]. */

@@ -328,6 +328,7 @@ __global__ void __launch_bounds__(FRONTS ? 512 : 1024) spicey_tran_kernel_grp(Sp
   GpuGroupExec ex{G, wgi, gs, gs + 1, 0u, false, (double *)smem,
                   R.prof ? R.prof + (size_t)blockIdx.x * SPICEY_PH_SLOTS : nullptr, (unsigned long long)wall_clock64(), gs + 16, 0u, 0u, 1u, 1u};
   ex.census();
+  if (R.force_abort && wgi == 0 && threadIdx.x == 0) __hip_atomic_store(gs + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (tests)
   spicey_tran_run<K, FRONTS>(ex, P, R, c, grp);
 }
 

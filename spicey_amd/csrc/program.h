@@ -244,4 +244,5 @@ struct SpiceyRun {
   const uint32_t *fs_first, *fs_list, *fs_owner;  // fs_owner[nFronts]: workgroup (of the group) that runs a front
   unsigned int *front_flags;
   int32_t front_lds_doubles;  // LDS scratch per workgroup (fronts that fit live there whole; tests shrink it to force the staged path)
+  int32_t force_abort;        // tests: group mode raises its abort word at start-up (exercises the host's one relaunch)
 };

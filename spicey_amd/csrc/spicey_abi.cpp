@@ -50,6 +50,11 @@ struct SpiceyHandle {
   double *d_Cv = nullptr, *d_Li = nullptr, *d_Dv = nullptr;
   int32_t *d_Son = nullptr;
   double *d_Cv0 = nullptr, *d_Li0 = nullptr, *d_Dv0 = nullptr;  // the descriptor's state, for spicey_reset_state
+  // group mode: the state as it entered the launch in flight (a launch that ends in the bounded-spin abort is repeated once)
+  double *d_Cv_s = nullptr, *d_Li_s = nullptr, *d_Dv_s = nullptr;
+  int32_t *d_Son_s = nullptr;
+  SpiceyRun grp_R{};      // that launch's arguments
+  int group_retries = 0;  // launches repeated so far (spicey_group_retries)
   int32_t *d_Son0 = nullptr;
   double *d_gstat = nullptr, *d_statv = nullptr, *d_rcoef = nullptr, *d_gW = nullptr, *d_dpar = nullptr;
   int32_t *d_status = nullptr;
@@ -118,7 +123,7 @@ extern "C" void spicey_destroy(SpiceyHandle *h) {
   if (!h) return;
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
   void *ptrs[] = {h->d_res, h->d_blob, h->d_R, h->d_C, h->d_L, h->d_Sron, h->d_Sroff, h->d_Svon, h->d_Svoff, h->d_Dis, h->d_Dn, h->d_Cv,
-                  h->d_Li, h->d_Dv, h->d_Son, h->d_Cv0, h->d_Li0, h->d_Dv0, h->d_Son0, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_Pstruct, h->d_Qstruct, h->d_Rstruct, h->d_gsync, h->d_gflags, h->d_front_ws, h->d_fs, h->d_front_flags, h->d_status, h->d_solves, h->d_prof};
+                  h->d_Li, h->d_Dv, h->d_Son, h->d_Cv0, h->d_Li0, h->d_Dv0, h->d_Son0, h->d_Cv_s, h->d_Li_s, h->d_Dv_s, h->d_Son_s, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_Pstruct, h->d_Qstruct, h->d_Rstruct, h->d_gsync, h->d_gflags, h->d_front_ws, h->d_fs, h->d_front_flags, h->d_status, h->d_solves, h->d_prof};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -322,6 +327,10 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
       if ((rc = upload(h, &h->d_gsync, nou, (size_t)h->grid * SPICEY_GRP_SYNC_WORDS)) != SPICEY_OK) return fail(rc);
       const int32_t *noi = nullptr;
       if ((rc = upload(h, &h->d_gflags, noi, (size_t)h->grid * 4)) != SPICEY_OK) return fail(rc);
+      if ((rc = upload(h, &h->d_Cv_s, nodbl, ni * P.nC)) != SPICEY_OK) return fail(rc);
+      if ((rc = upload(h, &h->d_Li_s, nodbl, ni * P.nL)) != SPICEY_OK) return fail(rc);
+      if ((rc = upload(h, &h->d_Dv_s, nodbl, ni * P.nD)) != SPICEY_OK) return fail(rc);
+      if ((rc = upload(h, &h->d_Son_s, noi, ni * P.nS)) != SPICEY_OK) return fail(rc);
     }
   }
   if (P.nFronts > 0) {
@@ -424,7 +433,18 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
     h->run_args = R;
     HIPCHK(h, hipMemcpyAsync(h->d_Rstruct, &h->run_args, sizeof(SpiceyRun), hipMemcpyHostToDevice, st));
   }
-  if (h->G > 1) HIPCHK(h, hipMemsetAsync(h->d_gsync, 0, (size_t)h->grid * SPICEY_GRP_SYNC_WORDS * sizeof(unsigned int), st));
+  if (h->G > 1) {
+    HIPCHK(h, hipMemsetAsync(h->d_gsync, 0, (size_t)h->grid * SPICEY_GRP_SYNC_WORDS * sizeof(unsigned int), st));
+    // the state entering this launch, for the one relaunch after a bounded-spin abort (spicey_sync)
+    const SpiceyProg &P = h->hp.hdr;
+    const size_t ni = (size_t)h->n_inst;
+    if (P.nC) HIPCHK(h, hipMemcpyAsync(h->d_Cv_s, h->d_Cv, ni * P.nC * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (P.nL) HIPCHK(h, hipMemcpyAsync(h->d_Li_s, h->d_Li, ni * P.nL * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (P.nD) HIPCHK(h, hipMemcpyAsync(h->d_Dv_s, h->d_Dv, ni * P.nD * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (P.nS) HIPCHK(h, hipMemcpyAsync(h->d_Son_s, h->d_Son, ni * P.nS * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    R.force_abort = getenv("SPICEY_TEST_FORCE_GROUP_ABORT") != nullptr ? 1 : 0;  // tests: the first attempt of every launch aborts
+    h->grp_R = R;
+  }
   HIPCHK(h, hipEventRecord(h->ev0, st));  // (argument upload and flag resets stay outside the timed kernel)
   if (h->interp == 2) {
     HIPCHK(h, spicey_launch_tran_v2(h->dprog, h->dres, h->d_Pstruct, h->d_Qstruct, h->d_Rstruct, h->K, h->grid, h->T, st, h->packed));
@@ -443,31 +463,56 @@ extern "C" int32_t spicey_sync(SpiceyHandle *h) {
   if (!h) return SPICEY_ERR_BAD_DESC;
   if (!h->pending) return SPICEY_OK;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->last_stream));
-  h->pending = false;
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_ms = ms;
   std::vector<int32_t> status((size_t)h->grid * 4);
   std::vector<unsigned long long> solves((size_t)h->grid);
-  HIPCHK(h, hipMemcpy(status.data(), h->d_status, status.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIPCHK(h, hipMemcpy(solves.data(), h->d_solves, solves.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  h->last_solves = 0;
-  for (auto s : solves) h->last_solves += (int64_t)s;
-  // earliest failure wins (the reference throws at the first singular solve)
   int best = -1;
-  for (int g = 0; g < h->grid; g++)
-    if (status[(size_t)g * 4] != 0 && (best < 0 || status[(size_t)g * 4 + 2] < status[(size_t)best * 4 + 2])) best = g;
-  if (best >= 0 && status[(size_t)best * 4] == 3) {
+  bool repeated = false;
+  for (int attempt = 0;; attempt++) {
+    HIPCHK(h, hipStreamSynchronize(h->last_stream));
+    h->pending = false;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_ms = ms;
+    HIPCHK(h, hipMemcpy(status.data(), h->d_status, status.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(solves.data(), h->d_solves, solves.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    h->last_solves = 0;
+    for (auto s : solves) h->last_solves += (int64_t)s;
+    // earliest failure wins (the reference throws at the first singular solve)
+    best = -1;
+    for (int g = 0; g < h->grid; g++)
+      if (status[(size_t)g * 4] != 0 && (best < 0 || status[(size_t)g * 4 + 2] < status[(size_t)best * 4 + 2])) best = g;
+    if (best < 0 || status[(size_t)best * 4] != 3) break;
     // (the first workgroup that gave up left a note in its group's barrier words, GpuGroupExec::note_timeout)
     unsigned int note[8] = {0};
     if (h->d_gsync) (void)hipMemcpy(note, h->d_gsync + (size_t)best * SPICEY_GRP_SYNC_WORDS, sizeof(note), hipMemcpyDeviceToHost);
     char buf[256];
     snprintf(buf, sizeof(buf), "cross-workgroup barrier timed out (group mode) at step %d: %s, workgroup %u (XCD %u), %s %u, waited for %u, saw %u",
-             status[(size_t)best * 4 + 2], note[2] == 2 ? "front hand-over" : note[2] == 3 ? "census barrier" : "group barrier", note[3], note[7],
-             note[2] == 2 ? "flag word" : "barrier", note[4], note[5], note[6]);
+             status[(size_t)best * 4 + 2], note[2] == 2 ? "front hand-over" : note[2] == 3 ? "census barrier" : note[2] == 1 ? "group barrier" : "abort word raised",
+             note[3], note[7], note[2] == 2 ? "flag word" : "barrier", note[4], note[5], note[6]);
     h->err = buf;
-    return SPICEY_ERR_HIP;
+    if (attempt > 0 || h->G <= 1) return SPICEY_ERR_HIP;
+    // The bounded spin turned what would have been a hang into an abort; nothing of the aborted launch is kept.  The
+    // launch is repeated ONCE from the state it started with (the kernel writes state only in its last step, but that
+    // step may be the one that aborted): same arguments, same stream, fresh barrier words and front flags.
+    h->group_retries++;
+    repeated = true;
+    fprintf(stderr, "spicey: %s -- repeating the launch once\n", buf);
+    const SpiceyProg &P = h->hp.hdr;
+    const size_t ni = (size_t)h->n_inst;
+    hipStream_t st = h->last_stream;
+    if (P.nC) HIPCHK(h, hipMemcpyAsync(h->d_Cv, h->d_Cv_s, ni * P.nC * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (P.nL) HIPCHK(h, hipMemcpyAsync(h->d_Li, h->d_Li_s, ni * P.nL * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (P.nD) HIPCHK(h, hipMemcpyAsync(h->d_Dv, h->d_Dv_s, ni * P.nD * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (P.nS) HIPCHK(h, hipMemcpyAsync(h->d_Son, h->d_Son_s, ni * P.nS * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemsetAsync(h->d_gsync, 0, (size_t)h->grid * SPICEY_GRP_SYNC_WORDS * sizeof(unsigned int), st));
+    if (P.nFronts > 0) HIPCHK(h, hipMemsetAsync(h->d_front_flags, 0, (size_t)h->grid * 2 * (size_t)P.nFronts * sizeof(unsigned int), st));
+    if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, (size_t)h->grid * h->G * 72 * sizeof(unsigned long long), st));
+    h->grp_R.force_abort = 0;
+    HIPCHK(h, hipEventRecord(h->ev0, st));
+    HIPCHK(h, spicey_launch_tran_grp(h->dprog, h->grp_R, h->K, h->grid, h->T, st));
+    HIPCHK(h, hipEventRecord(h->ev1, st));
+    h->pending = true;
   }
+  if (repeated && best < 0) h->err.clear();
   if (best >= 0) {
     char buf[160];
     snprintf(buf, sizeof(buf), "singular at inst %d step %d iter %d", status[(size_t)best * 4 + 1], status[(size_t)best * 4 + 2],
@@ -477,6 +522,8 @@ extern "C" int32_t spicey_sync(SpiceyHandle *h) {
   }
   return SPICEY_OK;
 }
+
+extern "C" int32_t spicey_group_retries(const SpiceyHandle *h) { return h ? h->group_retries : 0; }
 
 extern "C" int32_t spicey_run(SpiceyHandle *h, int64_t steps, double dt, const double *src_table, double *out_v, double *out_i,
                               int32_t *iters) {

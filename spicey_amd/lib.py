@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("SPICEY_HIP_LIB") or os.path.join(_HERE, "libspicey_hi
 _LIB = None
 
 EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "spicey_get_state", "spicey_set_state", "spicey_reset_state",
-           "spicey_last_solve_count",
+           "spicey_last_solve_count", "spicey_group_retries",
            "spicey_last_kernel_ms", "spicey_get_info", "spicey_last_error", "spicey_destroy", "spicey_version",
            "spicey_debug_phase_cycles", "spicey_debug_phase_cycles_wg",
            "spicey_create_multi", "spicey_run_multi", "spicey_get_state_multi", "spicey_multi_get_shard", "spicey_multi_last_solve_count",
@@ -49,6 +49,8 @@ def load():
     L.spicey_run_device.argtypes = [vp, C.c_int64, C.c_double, vp, vp, vp, vp, vp]
     L.spicey_sync.restype = C.c_int32
     L.spicey_sync.argtypes = [vp]
+    L.spicey_group_retries.restype = C.c_int32
+    L.spicey_group_retries.argtypes = [vp]
     L.spicey_get_state.restype = C.c_int32
     L.spicey_get_state.argtypes = [vp, f64p, f64p, f64p, i32p]
     L.spicey_set_state.restype = C.c_int32
@@ -171,6 +173,10 @@ class Handle:
 
     def solves(self) -> int:
         return self.L.spicey_last_solve_count(self.h)
+
+    def group_retries(self) -> int:
+        """Group-mode launches this handle repeated after a bounded-spin abort (include/spicey_hip.h, spicey_sync)."""
+        return self.L.spicey_group_retries(self.h)
 
     def kernel_ms(self) -> float:
         return self.L.spicey_last_kernel_ms(self.h)

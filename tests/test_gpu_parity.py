@@ -253,6 +253,42 @@ def test_group_mode_workgroups_cooperate_on_one_instance(oracle_backend):
     assert np.array_equal(got2["out_v"][0], first["out_v"][0]) and np.array_equal(got2["out_v"][1], first["out_v"][0])
 
 
+def test_group_mode_abort_is_repeated_once(monkeypatch, capfd):
+    """Every cross-workgroup wait of the group mode is a bounded spin; a launch whose spin runs out aborts as a whole and
+    spicey_sync repeats it ONCE from the state it started with (include/spicey_hip.h).  The test raises the abort word at
+    the start of every first attempt: two consecutive runs (the second continues from the first one's state), with dense
+    fronts and without, must give the bits, the final state and the solve counts of undisturbed runs."""
+    from spicey_amd.lib import Handle
+    ckt = parseNetlist(synth.rcd_mesh(20, seed=8, tran=".tran 1e-6 1e-5"))
+    dt, steps = abi.computeEffectiveTimeStep(1e-6, 1e-5)
+    flat = abi.flatten(ckt)
+    src = abi.source_table(ckt, dt, steps)
+    for kw in (dict(force_global=True, wgs_per_inst=4), dict(force_global=True, wgs_per_inst=7, front_cut=3)):
+        outs = {}
+        for forced in (False, True):
+            if forced:
+                monkeypatch.setenv("SPICEY_TEST_FORCE_GROUP_ABORT", "1")
+            else:
+                monkeypatch.delenv("SPICEY_TEST_FORCE_GROUP_ABORT", raising=False)
+            h = Handle(flat, **kw)
+            try:
+                a = h.run(steps, dt, src)
+                b = h.run(steps, dt, src)  # continues from the state the first run left
+                assert a["status"] == 0 and b["status"] == 0, (kw, forced, a["detail"], b["detail"])
+                outs[forced] = (a, b, h.state(), h.group_retries())
+            finally:
+                h.close()
+        monkeypatch.delenv("SPICEY_TEST_FORCE_GROUP_ABORT", raising=False)
+        assert outs[False][3] == 0 and outs[True][3] == 2
+        for i in (0, 1):
+            assert np.array_equal(outs[True][i]["out_v"], outs[False][i]["out_v"]) and np.array_equal(outs[True][i]["out_i"], outs[False][i]["out_i"])
+            assert np.array_equal(outs[True][i]["iters"], outs[False][i]["iters"]) and outs[True][i]["solves"] == outs[False][i]["solves"]
+        assert not np.array_equal(outs[False][0]["out_v"], outs[False][1]["out_v"])  # (the second run really starts elsewhere)
+        for k in outs[False][2]:
+            assert np.array_equal(outs[True][2][k], outs[False][2][k]), k
+    assert "repeating the launch once" in capfd.readouterr().err
+
+
 def test_config5_full_size_mesh(oracle_backend):
     """BASELINE configs[4] at FULL size: rcd_mesh(100x100), 10 001 unknowns, nnz(L+U) = 355 387, 297 levels — three
     timesteps against the oracle (the dense-GE restatement needs ~6 s per step at this size)."""
