@@ -18,7 +18,11 @@ def lib():
     if _LIB is None:
         # SPICEY_EMUL_ASAN=1 (with LD_PRELOAD=$(gcc -print-file-name=libasan.so)): the address / UB sanitizer build
         asan = os.environ.get("SPICEY_EMUL_ASAN") == "1"
-        subprocess.run(["make", "-s", "-C", _HERE] + (["asan"] if asan else []), check=True, stderr=subprocess.DEVNULL)
+        import fcntl
+        os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+        with open(os.path.join(_HERE, "_build", ".lock"), "w") as lk:  # (pytest-xdist workers: one build at a time)
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            subprocess.run(["make", "-s", "-C", _HERE] + (["asan"] if asan else []), check=True, stderr=subprocess.DEVNULL)
         L = C.CDLL(os.path.join(_HERE, "_build", "libspicey_emul_asan.so" if asan else "libspicey_emul.so"))
         f64p, i32p, i64p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
         L.spicey_emul_run.restype = C.c_int32
