@@ -197,6 +197,11 @@ int32_t spicey_debug_phase_cycles(SpiceyHandle *h, uint64_t *out, int32_t n);
  * 100 MHz wall-clock ticks per SECTION of the step: [1] B, [8] factor levels below the front cut, [9] fronts forward,
  * [10] fronts backward, [11] publish + group barrier, [12..20] inside the fronts, [40] backward levels, [4] Z. */
 int32_t spicey_debug_phase_cycles_wg(SpiceyHandle *h, int32_t wg, uint64_t *out, int32_t n);
+/* Diagnostics (SpiceyOptions.profile, circuits with dense fronts): per front of group `grp` four event times of the last
+ * run — forward: children assembled / done, backward: parent's unknowns there / done — in 100 MHz ticks since the owning
+ * workgroup entered the forward sweep, SUMMED over the solves (out[f*4+e]); meta[f*4+{0,1,2,3}] = pivots, boundary rows,
+ * parent front, owning workgroup.  Returns the number of fronts (0: nothing recorded / cap_fronts too small). */
+int32_t spicey_debug_front_ticks(SpiceyHandle *h, int32_t grp, uint64_t *out, int32_t *meta, int32_t cap_fronts);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Several devices behind one handle (SURVEY.md §8(b) "device ordinal(s)", §8(e)): the n_inst instances of the descriptor

@@ -39,6 +39,12 @@ struct FrontsRun {
   double *FW;       // this group's front workspace
   unsigned int *fl; // this group's done flags [2 nFronts]
   int T;            // threads of ONE workgroup
+  unsigned long long *ticks;  // this group's per-front event times (profiling), or null
+
+  // profiling: event `e` of front f happened now (ticks since this workgroup entered the forward sweep)
+  SPICEY_HD void stamp(uint32_t f, int e, unsigned long long t0) const {
+    if (ticks) ex.add_ticks(ticks + (size_t)f * 4 + e, t0);
+  }
 
   SPICEY_HD bool foreign(uint32_t f) const { return R.fs_owner[f] != (uint32_t)ex.wg(); }
   // an LDS-resident front: the block (Mp rows of Mp + 17) plus the 16 x 16 block of L and the reciprocal pivots
@@ -353,7 +359,7 @@ struct FrontsRun {
   }
   // Own data first (right-hand side after the forward sweep, last diagonal block): this part does not need the ancestors'
   // unknowns and runs BEFORE the front waits for its parent's workgroup; then the boundary product straight from W.
-  SPICEY_HD void solve(const SpiceyFront &F, bool wait_parent, unsigned int epoch) const {
+  SPICEY_HD void solve(const SpiceyFront &F, bool wait_parent, unsigned int epoch, uint32_t f, unsigned long long t0) const {
     const double *A = FW + F.off;
     double *lds = ex.lds();
     double *xs = lds, *tt = xs + F.Mp, *part = tt + F.Pp, *Db = part + (size_t)F.Pp * 4;  // Db: 16 x 16 diagonal block
@@ -364,6 +370,7 @@ struct FrontsRun {
       load_db(F, A, Db, t, F.Pp - SPICEY_FB);
     });
     if (wait_parent) ex.front_wait(fl + P.nFronts + F.parent, epoch);
+    stamp(f, 2, t0);
     ex.mark(SPICEY_PH_U0 + 10);
     ex.wg_phase([&](int t) {  // t = y_P - U_PB x_B: four partial sums per row, combined in a fixed order
       SPICEY_NOUNROLL
@@ -416,8 +423,9 @@ struct FrontsRun {
   }
 
   // ---- the two sweeps over this workgroup's share of the front tree -------------------------------------------
-  SPICEY_HD void forward(unsigned int epoch) const {
+  SPICEY_HD unsigned long long forward(unsigned int epoch) const {
     const int w = ex.wg();
+    const unsigned long long t0 = ticks ? ex.ticks_now() : 0ull;
     for (uint32_t s = R.fs_first[w]; s < R.fs_first[w + 1]; s++) {
       const uint32_t f = R.fs_list[s];
       const SpiceyFront F = P.fr[f];
@@ -426,6 +434,7 @@ struct FrontsRun {
         const int lda = F.Mp + SPICEY_FRONT_LDS_PAD;
         assemble_own(F, A, lda);
         assemble_children(F, A, lda, epoch);
+        stamp(f, 0, t0);
         ex.mark(SPICEY_PH_U0 + 5);
         factor_lds(F, A, lda, A + (size_t)F.Mp * lda);
         ex.mark(SPICEY_PH_U0 + 6);
@@ -434,24 +443,28 @@ struct FrontsRun {
       } else {
         assemble_own(F, FW + F.off, F.ld);
         assemble_children(F, FW + F.off, F.ld, epoch);
+        stamp(f, 0, t0);
         ex.mark(SPICEY_PH_U0 + 8);
         factor_global(F);
         ex.mark(SPICEY_PH_U0 + 9);
       }
       if (F.parent >= 0 && foreign((uint32_t)F.parent)) ex.front_post(fl + f, epoch);
+      stamp(f, 1, t0);
       ex.mark(SPICEY_PH_U0 + 12);
     }
+    return t0;
   }
-  SPICEY_HD void backward(unsigned int epoch) const {
+  SPICEY_HD void backward(unsigned int epoch, unsigned long long t0) const {
     const int w = ex.wg();
     for (uint32_t s = R.fs_first[w + 1]; s > R.fs_first[w]; s--) {
       const uint32_t f = R.fs_list[s - 1];
       const SpiceyFront F = P.fr[f];
-      solve(F, F.parent >= 0 && foreign((uint32_t)F.parent), epoch);
+      solve(F, F.parent >= 0 && foreign((uint32_t)F.parent), epoch, f, t0);
       ex.mark(SPICEY_PH_U0 + 11);
       bool any = false;
       for (uint32_t ci = 0; ci < F.child_n; ci++) any = any || foreign(P.fr_child[F.child0 + ci]);
       if (any) ex.front_post(fl + P.nFronts + f, epoch);
+      stamp(f, 3, t0);
     }
   }
 };

@@ -48,6 +48,12 @@ __device__ __forceinline__ void gpu_wave_lockstep_keep(int nlanes, int nsteps, F
 }
 
 struct GpuExec {
+  // profiling clock (100 MHz, the same counter on every CU) and an accumulator bump by one thread
+  __device__ __forceinline__ unsigned long long ticks_now() const { return (unsigned long long)wall_clock64(); }
+  __device__ __forceinline__ void add_ticks(unsigned long long *dst, unsigned long long t0) const {
+    if (threadIdx.x == 0) *dst += (unsigned long long)wall_clock64() - t0;
+  }
+
   unsigned long long *prof;  // null unless phase profiling was requested
   double *lds_;              // scratch for the dense fronts (null when the program has none)
   __device__ __forceinline__ int wg() const { return 0; }
@@ -124,6 +130,12 @@ __global__ void __launch_bounds__(FRONTS ? 512 : 1024) spicey_tran_kernel(Spicey
 // Guideline 16).  All G workgroups are co-resident by construction (the host launches at most one per CU) and every
 // spin is bounded: on a timeout the abort word is set, every workgroup leaves, and the run reports an error.
 struct GpuGroupExec {
+  // profiling clock (100 MHz, the same counter on every CU) and an accumulator bump by one thread
+  __device__ __forceinline__ unsigned long long ticks_now() const { return (unsigned long long)wall_clock64(); }
+  __device__ __forceinline__ void add_ticks(unsigned long long *dst, unsigned long long t0) const {
+    if (threadIdx.x == 0) *dst += (unsigned long long)wall_clock64() - t0;
+  }
+
   int G, wgi;
   unsigned int *counter, *abortf;
   unsigned int epoch;

@@ -245,4 +245,7 @@ struct SpiceyRun {
   unsigned int *front_flags;
   int32_t front_lds_doubles;  // LDS scratch per workgroup (fronts that fit live there whole; tests shrink it to force the staged path)
   int32_t force_abort;        // tests: group mode raises its abort word at start-up (exercises the host's one relaunch)
+  // profiling: per front {forward: children assembled, forward: done; backward: parent's unknowns there, backward: done},
+  // 100 MHz ticks since the owner entered the forward sweep of that solve, summed over the solves [n_groups][nFronts][4]
+  unsigned long long *front_ticks;
 };

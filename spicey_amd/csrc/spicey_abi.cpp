@@ -351,7 +351,8 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   const unsigned long long *noull = nullptr;
   if ((rc = upload(h, &h->d_solves, noull, (size_t)h->grid)) != SPICEY_OK) return fail(rc);
   if (h->opt.profile)
-    if ((rc = upload(h, &h->d_prof, noull, (size_t)h->grid * h->G * 72)) != SPICEY_OK) return fail(rc);
+    // (+ per-front event times behind the per-workgroup section timers)
+    if ((rc = upload(h, &h->d_prof, noull, (size_t)h->grid * h->G * 72 + (size_t)h->grid * 4 * (size_t)P.nFronts)) != SPICEY_OK) return fail(rc);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     h->err = "stream/event creation failed";
     return fail(SPICEY_ERR_HIP);
@@ -416,7 +417,8 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   R.gstat = h->d_gstat; R.statv = h->d_statv; R.rcoef = h->d_rcoef; R.gW = h->d_gW; R.dpar = h->d_dpar;
   R.src = d_src_table; R.out_v = d_out_v; R.out_i = d_out_i; R.iters = d_iters;
   R.status = h->d_status; R.solves = h->d_solves; R.prof = h->d_prof;
-  if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, (size_t)h->grid * h->G * 72 * sizeof(unsigned long long), st));
+  if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, ((size_t)h->grid * h->G * 72 + (size_t)h->grid * 4 * (size_t)h->hp.hdr.nFronts) * sizeof(unsigned long long), st));
+  R.front_ticks = (h->d_prof && h->hp.hdr.nFronts > 0) ? h->d_prof + (size_t)h->grid * h->G * 72 : nullptr;
   R.wgs_per_group = h->G;
   R.grp_sync = h->d_gsync;
   R.grp_flags = h->d_gflags;
@@ -505,7 +507,7 @@ extern "C" int32_t spicey_sync(SpiceyHandle *h) {
     if (P.nS) HIPCHK(h, hipMemcpyAsync(h->d_Son, h->d_Son_s, ni * P.nS * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipMemsetAsync(h->d_gsync, 0, (size_t)h->grid * SPICEY_GRP_SYNC_WORDS * sizeof(unsigned int), st));
     if (P.nFronts > 0) HIPCHK(h, hipMemsetAsync(h->d_front_flags, 0, (size_t)h->grid * 2 * (size_t)P.nFronts * sizeof(unsigned int), st));
-    if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, (size_t)h->grid * h->G * 72 * sizeof(unsigned long long), st));
+    if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, ((size_t)h->grid * h->G * 72 + (size_t)h->grid * 4 * (size_t)P.nFronts) * sizeof(unsigned long long), st));
     h->grp_R.force_abort = 0;
     HIPCHK(h, hipEventRecord(h->ev0, st));
     HIPCHK(h, spicey_launch_tran_grp(h->dprog, h->grp_R, h->K, h->grid, h->T, st));
@@ -644,6 +646,27 @@ extern "C" int32_t spicey_debug_phase_cycles_wg(SpiceyHandle *h, int32_t wg, uin
   if (hipMemcpy(tmp, h->d_prof + (size_t)wg * 72, sizeof(tmp), hipMemcpyDeviceToHost) != hipSuccess) return 0;
   for (int i = 0; i < n && i < 72; i++) out[i] = tmp[i];
   return 72;
+}
+
+// Per-front event times of group `grp` in the last run (profile option; program.h, SpiceyRun::front_ticks): out[f * 4 + e]
+// = 100 MHz ticks since the owner entered the forward sweep, SUMMED over the solves; also the fronts' shape and owner
+// (meta[f * 4 + {0: pivots, 1: boundary, 2: parent, 3: owning workgroup}]).  Returns the number of fronts.
+extern "C" int32_t spicey_debug_front_ticks(SpiceyHandle *h, int32_t grp, uint64_t *out, int32_t *meta, int32_t cap_fronts) {
+  if (!h || !out || !meta || !h->d_prof || grp < 0 || grp >= h->grid) return 0;
+  const int nf = h->hp.hdr.nFronts;
+  if (nf <= 0 || cap_fronts < nf) return 0;
+  if (spicey_sync(h) == SPICEY_ERR_HIP) return 0;
+  std::vector<unsigned long long> tmp((size_t)nf * 4);
+  if (hipMemcpy(tmp.data(), h->d_prof + (size_t)h->grid * h->G * 72 + (size_t)grp * 4 * nf, tmp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  for (size_t i = 0; i < tmp.size(); i++) out[i] = tmp[i];
+  std::vector<uint32_t> first, list;
+  spicey_build_front_schedule(h->hp, h->G, first, list);
+  for (int w = 0; w < h->G; w++)
+    for (uint32_t s2 = first[w]; s2 < first[w + 1]; s2++) meta[(size_t)list[s2] * 4 + 3] = w;
+  for (int f = 0; f < nf; f++) {
+    meta[(size_t)f * 4 + 0] = h->hp.fronts[f].p; meta[(size_t)f * 4 + 1] = h->hp.fronts[f].q; meta[(size_t)f * 4 + 2] = h->hp.fronts[f].parent;
+  }
+  return nf;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

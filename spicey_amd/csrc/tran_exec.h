@@ -1411,7 +1411,8 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
   // dense fronts above the cut (K = 1 only; the host enables them for nonlinear circuits, so `linear` is false then)
   const bool use_fronts = FRONTS && K == 1 && P.nFronts > 0 && R.front_ws != nullptr;
   FrontsRun<Exec> fr{ex, P, R, c.W, c.flags, c.inst[0], c.valid[0], use_fronts ? R.front_ws + (size_t)wg * (size_t)P.front_ws : nullptr,
-                     use_fronts ? R.front_flags + (size_t)wg * 2 * (size_t)P.nFronts : nullptr, ex.local_threads()};
+                     use_fronts ? R.front_flags + (size_t)wg * 2 * (size_t)P.nFronts : nullptr, ex.local_threads(),
+                     use_fronts && R.front_ticks ? R.front_ticks + (size_t)wg * 4 * (size_t)P.nFronts : nullptr};
   unsigned int fepoch = 0;
   for (int64_t step = 0; step <= R.steps && code == 0; step++) {
     if (ex.failed()) { code = 3; err_step = step; break; }  // a cross-workgroup barrier timed out (group mode only)
@@ -1458,9 +1459,9 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
         // upper tree: every workgroup sweeps its share of the fronts up, then down (flags between workgroups, no group
         // barrier inside); one group barrier afterwards publishes the upper unknowns to the levels below the cut
         fepoch++;
-        fr.forward(fepoch);
+        const unsigned long long t_sweep = fr.forward(fepoch);
         ex.mark(SPICEY_PH_U0 + 1);
-        fr.backward(fepoch);
+        fr.backward(fepoch, t_sweep);
         ex.mark(SPICEY_PH_U0 + 2);
         ex.local_phase([&](int tid) { if (tid == 0) c.W[(size_t)P.one_slot * K] = 1.0; });
         ex.sync();

@@ -21,7 +21,7 @@ _LIB = None
 EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "spicey_get_state", "spicey_set_state", "spicey_reset_state",
            "spicey_last_solve_count", "spicey_group_retries",
            "spicey_last_kernel_ms", "spicey_get_info", "spicey_last_error", "spicey_destroy", "spicey_version",
-           "spicey_debug_phase_cycles", "spicey_debug_phase_cycles_wg",
+           "spicey_debug_phase_cycles", "spicey_debug_phase_cycles_wg", "spicey_debug_front_ticks",
            "spicey_create_multi", "spicey_run_multi", "spicey_get_state_multi", "spicey_multi_get_shard", "spicey_multi_last_solve_count",
            "spicey_multi_last_kernel_ms", "spicey_multi_last_error", "spicey_destroy_multi",
            "spicey_ac_create", "spicey_ac_run", "spicey_ac_get_info", "spicey_ac_last_kernel_ms", "spicey_ac_last_error", "spicey_ac_destroy",
@@ -173,6 +173,17 @@ class Handle:
 
     def solves(self) -> int:
         return self.L.spicey_last_solve_count(self.h)
+
+    def front_ticks(self, grp: int = 0):
+        """(ticks[nf][4] uint64 summed over the solves, meta[nf][4] = pivots, boundary, parent, owner) of the last run
+        (profile=True, circuits with dense fronts); include/spicey_hip.h, spicey_debug_front_ticks."""
+        nf = self.info()["n_fronts"]
+        t = np.zeros((max(nf, 1), 4), np.uint64)
+        m = np.zeros((max(nf, 1), 4), np.int32)
+        self.L.spicey_debug_front_ticks.restype = C.c_int32
+        self.L.spicey_debug_front_ticks.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.c_int32]
+        got = self.L.spicey_debug_front_ticks(self.h, grp, t.ctypes.data_as(C.POINTER(C.c_uint64)), m.ctypes.data_as(C.POINTER(C.c_int32)), nf)
+        return t[:got], m[:got]
 
     def group_retries(self) -> int:
         """Group-mode launches this handle repeated after a bounded-spin abort (include/spicey_hip.h, spicey_sync)."""

@@ -32,6 +32,8 @@ struct SeqExec {
   int wg() const { return 0; }
   // work the GPU splits over a group's workgroups without a barrier in between: the emulator plays `virt_wgs` workgroups
   // one after the other, each through ALL its phases (a dependence between two of them would change the result)
+  unsigned long long ticks_now() const { return 0; }
+  void add_ticks(unsigned long long *, unsigned long long) const {}
   int virt_wgs = 1;
   template <class F>
   void for_each_wg(F f) { for (int g = 0; g < virt_wgs; g++) f(g, virt_wgs); }
