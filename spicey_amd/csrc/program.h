@@ -161,9 +161,11 @@ struct SpiceyProg {
   //     ALL levels below the cut with workgroup barriers only.  Targets above the cut (front entries, upper right-hand
   //     sides) collect their products of every level below the cut, in (level, pivot) order, in the one all-workgroup
   //     phase stored as factor level `front_cut`.  bin_bk: the same for the backward levels below the cut (targets = rows
-  //     of the bin's subtrees), after the interface phase.
+  //     of the bin's subtrees) AND for the interface tasks (backward level `front_cut`: their rows lie below the cut as
+  //     well and the upper unknowns they read were published by the barrier behind the fronts): no group barrier between
+  //     the interface and the levels below it either.
   int32_t nBins, pad_bins_;
-  const uint32_t *bin_upd, *bin_bk;  // [front_cut][nBins + 1]
+  const uint32_t *bin_upd, *bin_bk;  // [front_cut][nBins + 1], [front_cut + 1][nBins + 1]
 
   // --- natural (reference) numbering of what the workspace holds, for the AC sweep's dense partial-pivoting fallback
   //     (ac_exec.h): entry id -> row / column of A as simulateAC.ts builds it (node - 1, branches behind the nodes);

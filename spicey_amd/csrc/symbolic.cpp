@@ -1025,7 +1025,7 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
       i = j;
     }
     hp.n_bk_products += (int64_t)prods.size();
-    if (nBins > 0 && l < Lc) {  // rows of one bin's subtrees together (program.h)
+    if (nBins > 0 && l <= Lc) {  // rows of one bin's subtrees together (program.h); l == Lc: the interface tasks, whose rows lie below the cut too
       std::vector<std::vector<std::pair<uint32_t, std::vector<uint32_t>>>> per_bin(nBins);
       for (auto &tk : tasks) per_bin[bin_of[(int)tk.first - nLU]].push_back(std::move(tk));
       for (int b = 0; b < nBins; b++) {

@@ -1475,15 +1475,14 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
         // the interface phase included: those go to all workgroups, one group barrier each)
         bool local_run = false;
         int l_last = 0;
-        if (use_fronts && P.nBins > 0) l_last = P.front_cut;  // (the levels below follow, bin by bin)
+        if (use_fronts && P.nBins > 0) l_last = P.front_cut + 1;  // (the interface and the levels below it follow, bin by bin)
         for (int l = use_fronts ? P.front_cut : P.nLevels - 1; l >= l_last; l--) {  // (backward level `front_cut`: the interface)
           const uint32_t nsl = P.bk_lvl_slice[l + 1] - P.bk_lvl_slice[l];
           if (nsl == 0) continue;
           if (use_fronts && nsl > 16) {
             if (local_run) ex.sync();
             local_run = false;
-            if (l_last > 0 && l == l_last) ex.phase_marked(SPICEY_PH_U0 + 23, [&](int tid) { ph.k_level(tid, l); });
-            else ex.phase(SPICEY_PH_K0 + 31, [&](int tid) { ph.k_level(tid, l); });
+            ex.phase(SPICEY_PH_K0 + 31, [&](int tid) { ph.k_level(tid, l); });
             continue;
           }
           ex.local_phase([&](int tid) { phl.k_level(tid, l); });
@@ -1494,21 +1493,21 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
           local_run = true;  // (one group barrier behind the bins)
           ex.mark(SPICEY_PH_U0 + 20);
           ex.for_each_wg([&](int g, int G) {
-            for (int l = P.front_cut - 1; l >= 0; l--) ex.wg_phase([&](int tid) { phl.k_bins(tid, l, g, G); });
+            for (int l = P.front_cut; l >= 0; l--) ex.wg_phase([&](int tid) { phl.k_bins(tid, l, g, G); });
           });
           ex.mark(SPICEY_PH_U0 + 21);
         }
         if (local_run || !use_fronts) ex.sync();
       } else {
         int l_last = 0;
-        if (use_fronts && P.nBins > 0) l_last = P.front_cut;
+        if (use_fronts && P.nBins > 0) l_last = P.front_cut + 1;
         for (int l = use_fronts ? P.front_cut : P.nLevels - 1; l >= l_last; l--) {
           if (P.bk_lvl_slice[l] == P.bk_lvl_slice[l + 1]) continue;
           ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) { ph.k_level(tid, l); });
         }
         if constexpr (FRONTS) if (l_last > 0)
           ex.for_each_wg([&](int g, int G) {
-            for (int l = P.front_cut - 1; l >= 0; l--) ex.wg_phase([&](int tid) { phl.k_bins(tid, l, g, G); });
+            for (int l = P.front_cut; l >= 0; l--) ex.wg_phase([&](int tid) { phl.k_bins(tid, l, g, G); });
           });
       }
       ex.phase(SPICEY_PH_K0, [&](int tid) { ph.k_scale(tid); });
