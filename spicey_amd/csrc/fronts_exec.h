@@ -426,6 +426,14 @@ struct FrontsRun {
   SPICEY_HD unsigned long long forward(unsigned int epoch) const {
     const int w = ex.wg();
     const unsigned long long t0 = ticks ? ex.ticks_now() : 0ull;
+    // A front that is staged through the workspace takes its own entries over from W straight into the workspace — that
+    // does not need the LDS, so it is done first thing in the sweep (what it reads is final since the interface phase):
+    // by the time such a front's children are there, only their blocks are left to add (the 15 k gathered entries of the
+    // top fronts of a 100 x 100 mesh are 24 us each, which used to sit between the last child and the first panel)
+    for (uint32_t s = R.fs_first[w]; s < R.fs_first[w + 1]; s++) {
+      const SpiceyFront F = P.fr[R.fs_list[s]];
+      if (!fits_lds(F)) assemble_own(F, FW + F.off, F.ld);
+    }
     for (uint32_t s = R.fs_first[w]; s < R.fs_first[w + 1]; s++) {
       const uint32_t f = R.fs_list[s];
       const SpiceyFront F = P.fr[f];
@@ -441,7 +449,6 @@ struct FrontsRun {
         store_lds_front(F, A, lda);
         ex.mark(SPICEY_PH_U0 + 7);
       } else {
-        assemble_own(F, FW + F.off, F.ld);
         assemble_children(F, FW + F.off, F.ld, epoch);
         stamp(f, 0, t0);
         ex.mark(SPICEY_PH_U0 + 8);
