@@ -761,6 +761,18 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
       hp.front_work.push_back(work / 64.0 + 12000.0 + 8000.0 * (f.Pp / 16) + (f.Mp > 128 ? 60000.0 : 0.0));
     }
     if (off >= ((uint64_t)1 << 31) || max_mp > 448) ok = false;  // 32-bit offsets; panels of the largest front must fit LDS
+    // A front adds its children's blocks in a fixed order and waits for each in turn: the child expected LAST (the longest
+    // chain of weights below it — a property of the tree, not of the schedule) goes last, so that the others are in by
+    // the time it arrives
+    if (ok && !getenv("SPICEY_FRONT_CHILD_ORDER_ID")) {
+      std::vector<double> fin(hp.fronts.size(), 0.0);
+      for (size_t fi = 0; fi < hp.fronts.size(); fi++) {  // children precede parents
+        double last = 0.0;
+        for (int c : kids[fi]) last = std::max(last, fin[c]);
+        fin[fi] = last + hp.front_work[fi];
+        std::stable_sort(kids[fi].begin(), kids[fi].end(), [&](int a, int b) { return fin[a] < fin[b]; });
+      }
+    }
     for (size_t fi = 0; fi < hp.fronts.size() && ok; fi++) {
       SpiceyFront &f = hp.fronts[fi];
       f.child0 = (uint32_t)hp.fr_child.size();
