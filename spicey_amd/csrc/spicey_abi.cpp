@@ -317,7 +317,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
       // workgroup per subtree: up to 128 CUs for a single instance (measured on rcd_mesh(100): 32 / 48 / 64 / 96 / 128
       // workgroups = 0.78 / 0.71 / 0.70 / 0.69 / 0.68 ms per step); without them every one of ~600 barriers per step grows with G)
       const int gmax = P.nFronts > 0 ? 128 : 16;
-      if (K <= 2 && P.nLU >= 40000)
+      if (K <= 2 && (P.nLU >= 40000 || P.nFronts > 0))
         while (G * 2 <= gmax && h->grid * G * 2 <= ncu) G *= 2;
     }
     if (h->grid * G > ncu) G = std::max(1, ncu / h->grid);

@@ -676,7 +676,11 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   if (Lc < 0) {
     // automatic: only where the long single-pivot chains of the top separators dominate (large, nonlinear circuits;
     // a linear circuit reuses its factors and keeps the task lists)
-    Lc = (nD + nS > 0 && nLU >= 40000 && nLevels > 24 && !hp.structurally_singular) ? 10 : 0;
+    // A handful of instances cannot fill the chip one workgroup each: there the fronts (with a group of workgroups per
+    // instance) win from much smaller circuits on — measured on R/C/diode meshes, one instance: 20 x 20 (nnz(L+U) 7.5 k,
+    // 51 levels) 0.151 -> 0.112 ms per step, 24 x 24 0.220 -> 0.134, 34 x 34 0.907 -> 0.168; 16 x 16 (4.3 k) is the tie.
+    const int64_t min_lu = d->n_inst <= 16 ? 6000 : 40000;
+    Lc = (nD + nS > 0 && nLU >= min_lu && nLevels > 24 && !hp.structurally_singular) ? 10 : 0;
     if (const char *e = getenv("SPICEY_FRONT_CUT")) Lc = atoi(e);  // experiments
   }
   if (Lc >= nLevels || hp.structurally_singular) Lc = 0;
