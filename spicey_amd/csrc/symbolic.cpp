@@ -676,10 +676,16 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   if (Lc < 0) {
     // automatic: only where the long single-pivot chains of the top separators dominate (large, nonlinear circuits;
     // a linear circuit reuses its factors and keeps the task lists)
-    // A handful of instances cannot fill the chip one workgroup each: there the fronts (with a group of workgroups per
+    // Up to 128 instances cannot fill the chip one workgroup each: there the fronts (with a group of workgroups per
     // instance) win from much smaller circuits on — measured on R/C/diode meshes, one instance: 20 x 20 (nnz(L+U) 7.5 k,
     // 51 levels) 0.151 -> 0.112 ms per step, 24 x 24 0.220 -> 0.134, 34 x 34 0.907 -> 0.168; 16 x 16 (4.3 k) is the tie.
-    const int64_t min_lu = d->n_inst <= 16 ? 6000 : 40000;
+    // Batches: 64 instances of the 34 x 34 mesh 0.893 -> 0.340 ms per step of the whole batch (4 workgroups each), 32:
+    // 0.907 -> 0.271, 64 of the 24 x 24 mesh (which fits LDS) 0.278 -> 0.207; and a circuit too large for LDS gains even
+    // with one workgroup per instance (256 x 34 x 34: 0.912 -> 0.814).
+    // Where the circuit fits LDS, the 16-bit interpreter (one workgroup per instance) is the alternative and wins once a
+    // group would be smaller than 8 workgroups (24 x 24: 32 instances 0.225 -> 0.186 with fronts, 64: 0.225 -> 0.209, 128:
+    // 0.225 -> 0.304; 20 x 20 x 64: 0.152 -> 0.185): below ~16 k entries the fronts are for up to 32 instances only.
+    const int64_t min_lu = d->n_inst <= 32 ? 6000 : 16000;
     Lc = (nD + nS > 0 && nLU >= min_lu && nLevels > 24 && !hp.structurally_singular) ? 10 : 0;
     if (const char *e = getenv("SPICEY_FRONT_CUT")) Lc = atoi(e);  // experiments
   }
