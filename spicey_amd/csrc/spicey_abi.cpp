@@ -317,9 +317,9 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
       // workgroup per subtree: up to 128 CUs for a single instance (measured on rcd_mesh(100): 32 / 48 / 64 / 96 / 128
       // workgroups = 0.78 / 0.71 / 0.70 / 0.69 / 0.68 ms per step); without them every one of ~600 barriers per step grows with G)
       const int gmax = P.nFronts > 0 ? 128 : 16;
-      // (the workspace is in HBM / L2 here: from ~16 k entries on the extra CUs pay for the group barriers also without
+      // (the workspace is in HBM / L2 here: from ~10 k entries on (what no longer fits LDS) the extra CUs pay for the group barriers also without
       // fronts — one diode_chain(4000) 68 -> 60 us per step, (8000) 119 -> 77, rc_ladder(8000) 80 -> 66 at G = 16)
-      if (K <= 2 && (P.nLU >= 16000 || P.nFronts > 0))
+      if (K <= 2 && (P.nLU >= 10000 || P.nFronts > 0))
         while (G * 2 <= gmax && h->grid * G * 2 <= ncu) G *= 2;
     }
     if (h->grid * G > ncu) G = std::max(1, ncu / h->grid);

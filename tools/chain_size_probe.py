@@ -1,14 +1,16 @@
+#!/usr/bin/env python3
+"""One long chain / ladder on the GPU: automatic choice against 4 and 16 cooperating workgroups (where group mode starts to pay)."""
 import sys, os, time
 sys.path.insert(0, '/root/repo')
 import numpy as np
 from spicey_amd import abi, synth
 from spicey_amd.netlist import parseNetlist
 from spicey_amd.lib import Handle
-for wl, n in (("diode_chain", 2000), ("diode_chain", 4000), ("diode_chain", 8000), ("rc_ladder", 8000)):
+for wl, n in (("diode_chain", 2000), ("diode_chain", 2600), ("diode_chain", 3200), ("diode_chain", 4000), ("diode_chain", 8000), ("rc_ladder", 8000)):
     steps = 200
     ckt = parseNetlist(getattr(synth, wl)(n, tran=f".tran 1e-6 {steps*1e-6!r}"))
     flat = abi.flatten(ckt); src = abi.source_table(ckt, 1e-6, steps)
-    for G in (0, 4, 16, 0):
+    for G in (0, 1, 4, 16, 1):
         try:
             h = Handle(flat, wgs_per_inst=G)
         except Exception as e:
