@@ -13,9 +13,11 @@ value = total solves (= sum of iterations over steps over instances over ranks) 
 solve is one pass of simulateTRAN.ts:152-160.
 
 Multi-GPU: instances are block-partitioned over ranks, one process per GPU, no
-data-path collective (weak scaling: --batch instances PER GPU).  RCCL broadcasts the shared source table
-from rank 0 before the run and gathers the probe-filtered results (simulateTRAN.ts:240-249 is the
-filter) to rank 0 after it; the gather is timed separately (`gather_ms`), outside the timed region.
+data-path collective (weak scaling: --batch instances PER GPU).  Rank 0 holds the parsed batch: RCCL broadcasts
+the shared topology and the source table, scatters every rank's block of per-instance parameters before the
+run, and gathers the probe-filtered results (simulateTRAN.ts:240-249 is the filter) to rank 0 after it; the
+gather is timed separately (`gather_ms`), outside the timed region.  With N > 1 the ranks must sit on N
+distinct devices (PCI bus ids are compared) or the run exits non-zero.
 `python3 bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (fresh child
 processes, before anything touches the GPU); under `python -m torch.distributed.run` it joins the job and
 checks that the world size is N.
@@ -145,7 +147,8 @@ def cpu_baseline(workload, n, seconds_target=12.0):
                       f"{os.cpu_count()} logical cores, 1 used)",
             "reference_js": {"value": 28.7 if workload == "diode_chain" else 22.4, "unit": "solves/s", "cores": 1,
                              "where": "the reference's own TypeScript path (type-erased, Node 12) timed in the BUILD container "
-                                      "(Xeon 2.1 GHz) while generating tests/golden/*_full.json — not this box; Node is absent here"}}
+                                      "(Xeon 2.1 GHz) while generating tests/golden/*_full.json — a build-container figure: the "
+                                      "reference's source does not travel to the GPU box, so it cannot be timed there"}}
 
 
 def run_rank(args):
@@ -172,9 +175,18 @@ def run_rank(args):
     if sdist.world() != args.gpus:
         raise SystemExit(f"communicator has {sdist.world()} ranks, --gpus says {args.gpus}")
     n_gpus = world
+    if world > 1:
+        import torch.distributed as tdist
+        if tdist.get_world_size() != args.gpus:
+            raise SystemExit(f"torch.distributed world size {tdist.get_world_size()} != --gpus {args.gpus}")
     props = torch.cuda.get_device_properties(local_rank)
+    pci = (int(getattr(props, "pci_domain_id", 0)) << 16) | (int(getattr(props, "pci_bus_id", local_rank)) << 8) | int(getattr(props, "pci_device_id", 0))
     log(f"[rank {rank}/{world}] device cuda:{local_rank} = {props.name}, pci {getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}, "
         f"{props.total_memory / 2**30:.0f} GiB, {props.multi_processor_count} CUs")
+    try:
+        pci_ids = sdist.assert_distinct_devices(pci, dev)  # N ranks on fewer than N GPUs: exit non-zero, no JSON line
+    except RuntimeError as e:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: {e}")
 
     B, n, tsteps = args.batch, args.nodes, args.timesteps
     dt = 1e-6
@@ -188,7 +200,16 @@ def run_rank(args):
     # ---- instance shard of this rank: weak scaling, B instances per GPU, seeds = global instance id + 1
     n_total = B * world
     mine = sdist.shard_range(n_total)
-    flat, _, _, _ = synth.chain_batch(args.workload, n, [i + 1 for i in mine], tran=tran)
+    # rank 0 holds the parsed batch (all instances of all ranks); topology by broadcast, each rank's block of the
+    # per-instance parameters by scatter (spicey_amd/dist.py; §8(e): ~32 KB of topology, 32 KB per instance)
+    full = None
+    if rank == 0:
+        full, _, _, _ = synth.chain_batch(args.workload, n, range(1, n_total + 1), tran=tran)
+    t_h = time.perf_counter()
+    topo = sdist.broadcast_topology(full, dev)
+    flat = sdist.scatter_params_from_root(topo, full, n_total, dev)
+    handout_ms = (time.perf_counter() - t_h) * 1e3
+    del full
 
     def alloc_and_make(batch_flat):
         h = Handle(batch_flat, device=local_rank, threads=args.threads, inst_per_wg=args.inst_per_wg, geometry=args.geometry)
@@ -256,6 +277,15 @@ def run_rank(args):
         wkey = f"{args.workload}:{n}:{tsteps}:{B}:{int(not args.no_currents)}"
         traffic, traffic_src, valu = committed_pmc(solves_per_launch, wkey)
         result_bytes = 8.0 * (info["n_out"] + (0 if args.no_currents else info["n_cur"])) * solves_per_launch
+        # LEAD roofline figure = what the kernel really moves to and from HBM per launch / its measured duration / 8 TB/s:
+        # counter traffic of the committed PMC passes of this same command where they exist (counters cannot be read from
+        # inside a timed run), else the compulsory part that is known exactly — the result stream this launch wrote.  The
+        # SURVEY 8(d) formula figure (bytes a STREAMING implementation would move) is kept as `frac_formula`: this kernel keeps
+        # matrix and factors on chip, so that figure can exceed 1 and is no utilisation.
+        moved = traffic if traffic else result_bytes
+        moved_gbs = moved / (k_ms * 1e-3) / 1e9
+        if moved_gbs > HBM_PEAK_GBS:
+            raise SystemExit(f"bench.py: {moved_gbs:.0f} GB/s of HBM traffic is above the {HBM_PEAK_GBS:.0f} GB/s peak: the timing or the byte count is wrong")
         rec = {
             "metric": "Newton-LU timestep solves/sec, 1000-node netlist",
             "value": total_solves / el,
@@ -283,10 +313,14 @@ def run_rank(args):
                 "resident_tasks": info["resident_tasks"], "streamed_tasks": info["streamed_tasks"],
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "frac_means": "SURVEY.md §8(d) ALGORITHMIC bytes (what a streaming implementation would move) per second / 8 TB/s; "
-                              "this kernel keeps matrix and factors on chip, so its real HBM traffic is `traffic` and its real HBM "
-                              "utilisation is `hbm_utilisation`; the limiter is VALU issue + dependent LDS chains (`valu_issue_frac`)",
+                "bound": "hbm", "achieved": moved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved_gbs / HBM_PEAK_GBS,
+                "frac_means": ("HBM bytes per launch from the PMC counters (2*FETCH_SIZE + WRITE_SIZE of the committed passes of this same "
+                               "command)" if traffic else "HBM bytes of the result stream this launch wrote (no committed PMC pass for this workload)")
+                              + " / measured kernel time / 8 TB/s.  The kernel is NOT bandwidth-bound: matrix, factors and state stay on chip "
+                              "(LDS + registers), HBM sees the result stream and a few KB of task records per solve; the limiter is VALU "
+                              "issue + dependent LDS chains (`valu_issue_frac`).  `frac_formula` = SURVEY.md 8(d) ALGORITHMIC bytes (what a "
+                              "streaming implementation would move) per second / 8 TB/s, kept for comparison across rounds; it can exceed 1",
+                "achieved_formula": achieved, "frac_formula": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
                 "hbm_utilisation": (traffic / (k_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)) if traffic else None,
                 "hbm_utilisation_results_only": result_bytes / (k_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
@@ -295,6 +329,8 @@ def run_rank(args):
                 "algorithmic_bytes_own_ordering": algo_own, "solves_per_launch": solves_per_launch, "kernel_ms": k_ms,
                 "kernel": "spicey_tran_kernel_v2" if info.get("interpreter") == 2 else "spicey_tran_kernel",
             },
+            "handout": {"ms": handout_ms, "what": "topology broadcast + per-instance parameter scatter from rank 0 (RCCL; before the timed region)",
+                        "devices_pci": pci_ids},
             "gather": {"ms": gather_ms, "bytes_to_root": int(n_total * (tsteps + 1) * len(cols) * 8), "probe_columns": cols,
                        "what": "probe-filtered node voltages of every instance of every rank gathered to rank 0 (RCCL gather); "
                                "not part of the timed region"},
@@ -332,7 +368,7 @@ def run_rank(args):
                                       "threads": i1["threads"], "geometry": i1["geometry"],
                                       "what": f"ONE {args.workload}({n}) netlist, {tsteps} timesteps: BASELINE configs as written"}
             h1.close()
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:  # rank 0's host cores, at every N
             rec["cpu_baseline"] = cpu_baseline(args.workload, n)
         print(json.dumps(rec), flush=True)
         if not rec["parity_ok"]:

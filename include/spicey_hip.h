@@ -16,6 +16,18 @@
  * C++ types.  A handle owns its device memory and is not thread-safe; distinct handles may be
  * used from distinct threads.  The library never calls abort()/exit().
  *
+ * Launch admission (one rule per DEVICE, enforced inside the library).  A large instance may run on several cooperating
+ * workgroups that wait for one another inside the kernel ("group mode", SpiceyInfo.wgs_per_inst > 1): such a launch only
+ * makes progress while ALL its workgroups are resident, one per CU.  Therefore (a) a group is sized from the runtime's
+ * occupancy answer for the very kernel and LDS size it launches, at most one workgroup per CU; (b) a group-mode launch
+ * starts only after every transient launch this library has enqueued on that device before it has finished, and no
+ * later transient launch of the library starts before the group-mode launch has finished — whatever handles, streams
+ * and host threads they come from (stream-ordered event waits, nothing blocks on the host; launches that are not
+ * group-mode stay concurrent with each other); (c) every cross-workgroup wait is bounded in time
+ * (SpiceyOptions.group_timeout_ms): a launch whose wait runs out aborts as a whole with SPICEY_ERR_HIP and the waiter's
+ * position in spicey_last_error() — it never hangs.  What the library cannot see are kernels of OTHER code on the same
+ * device: keep long-running foreign kernels off the device while a group-mode run is in flight, or raise the timeout.
+ *
  * Conventions
  *   node ids      0 = ground, 1..n_nodes = non-ground nodes (NodeIndex.ts:28-31: row = id-1)
  *   unknowns      x[0..n_nodes-1] node voltages, x[n_nodes+k] = branch current of source k
@@ -36,7 +48,7 @@
 extern "C" {
 #endif
 
-#define SPICEY_ABI_VERSION 1
+#define SPICEY_ABI_VERSION 2 /* 2: SpiceyOptions grew (group_retry, group_timeout_ms, diagnostics) */
 
 /* status codes (SURVEY.md §8(b) "Errors") */
 #define SPICEY_OK 0
@@ -102,6 +114,14 @@ typedef struct SpiceyOptions {
   int32_t front_cut;     /* dense fronts (large instances): pivots of elimination-tree level >= front_cut are factored as
                             dense supernodal fronts (LDS-staged panels, MFMA trailing updates) instead of one
                             barrier-separated level per pivot.  0 = auto (large nonlinear circuits), -1 = never, > 0 = this level */
+  int32_t group_retry;   /* group mode: 1 = a launch that ends in the bounded-wait abort is repeated ONCE from the state it
+                            started with (spicey_sync); 0 (default) = the abort is reported as SPICEY_ERR_HIP */
+  int32_t group_timeout_ms; /* group mode: longest single cross-workgroup wait before the launch aborts; 0 = 5000 */
+  int32_t diagnostics;   /* bit 0: count the solves whose stamped matrix has a column with 0 < |a_ik| < 1e-15 max_j |a_jk| — the
+                                   situation in which the reference's `if (Math.abs(f) < EPS) continue` (solveReal.ts:45) drops a
+                                   row update that this library performs (spicey_last_skip_risk);
+                            bit 1: record per step the one-shot linearisation error max_d |vd_new - vd_lin| over the diodes
+                                   (spicey_get_lin_err); diagnostic only, never changes an iteration count */
 } SpiceyOptions;
 
 typedef struct SpiceyInfo {
@@ -156,12 +176,17 @@ int32_t spicey_run(SpiceyHandle *h, int64_t steps, double dt, const double *src_
 int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, const double *d_src_table,
                           double *d_out_v, double *d_out_i, int32_t *d_iters, void *stream);
 /* Wait for enqueued runs; returns SPICEY_ERR_SINGULAR etc. like spicey_run.
- * Group mode (several workgroups per instance): every cross-workgroup wait is a bounded spin; a launch whose spin runs
- * out aborts as a whole (nothing of it is kept) and is repeated ONCE from the state it started with, on the same stream;
- * a second abort returns SPICEY_ERR_HIP with the first waiter's position in spicey_last_error(). */
+ * Group mode (several workgroups per instance): every cross-workgroup wait is bounded in time; a launch whose wait runs
+ * out aborts as a whole (nothing of it is kept): SPICEY_ERR_HIP with the first waiter's position (which wait, which
+ * workgroup on which XCD, the value it waited for and the value it saw) in spicey_last_error() and on stderr.  Only with
+ * SpiceyOptions.group_retry = 1 is the launch repeated ONCE from the state it started with, on the same stream; the
+ * text of the aborted attempt then stays in spicey_last_error() (prefixed "recovered: ") although the call returns OK. */
 int32_t spicey_sync(SpiceyHandle *h);
 /* Number of launches this handle has repeated that way (0 in a healthy run; each is also reported on stderr). */
 int32_t spicey_group_retries(const SpiceyHandle *h);
+/* Group mode, summed over this handle's launches: waits that only the read-modify-write poll saw satisfied, i.e. where the
+ * plain sc1 load poll kept returning an older value (kernels.hip, spin_until).  0 in a healthy run. */
+int64_t spicey_group_stale_polls(const SpiceyHandle *h);
 
 /* Final state after the last run (write-back to ckt: simulateTRAN.ts:221-237,122-124).
  * Any pointer may be NULL.  Arrays are [n_inst][n<kind>]. */
@@ -180,6 +205,21 @@ int32_t spicey_reset_state(SpiceyHandle *h, void *stream);
 
 /* Total solves (= sum of iterations) executed by the last run, all instances. */
 int64_t spicey_last_solve_count(SpiceyHandle *h);
+/* Diagnostics (SpiceyOptions.diagnostics bit 0).  The reference eliminates with partial pivoting and skips a row update whose
+ * multiplier a_ik / pivot is below 1e-15 (`if (Math.abs(f) < EPS) continue`, solveReal.ts:45): a nonzero coupling dropped —
+ * floor conductances (diode gd 1e-12 S, switch 1/Roff) next to a clamped diode, a milliohm resistor or a large C/dt.  A sparse
+ * static pivot order cannot reproduce that entry for entry; this library PERFORMS those updates (the physically consistent
+ * answer) and says when the situation occurs: the number of (solve, column) pairs of the last run in which the stamped
+ * matrix column held a nonzero entry below 1e-15 x the column's largest magnitude (per instance in per_inst[n_inst] if not
+ * NULL; the return value is the sum; -1 without the option).  0 means the reference took no such shortcut on the stamped
+ * matrix and the two results agree to the 1e-9 parity bar; > 0 means the reference's own result may differ from this one by
+ * up to |v_k| * |a_ik| / a_ii per flagged coupling ("Where the reference skips row updates"). */
+int64_t spicey_last_skip_risk(SpiceyHandle *h, int64_t *per_inst);
+/* Diagnostics (SpiceyOptions.diagnostics bit 1): out[n_inst][steps+1] = per step the largest |vd(x) - vd_lin| over the diodes,
+ * vd_lin being the junction voltage the step's LAST solve was linearised at (vdPrev on iteration 0, the previous iterate
+ * afterwards: simulateTRAN.ts:81-85).  The reference iterates only on switch flips and never looks at this quantity; it is
+ * reported, not acted on: iteration counts and results are identical with and without the option. */
+int32_t spicey_get_lin_err(SpiceyHandle *h, double *out);
 /* Duration in ms of the last run's kernel, measured with HIP events on the launch stream. */
 double spicey_last_kernel_ms(SpiceyHandle *h);
 
@@ -209,7 +249,8 @@ int32_t spicey_debug_front_ticks(SpiceyHandle *h, int32_t grp, uint64_t *out, in
  * spicey_amd/dist.py), one SpiceyHandle + stream per device inside THIS process; spicey_run_multi launches every shard
  * from its own host thread and each shard's results land directly in its slice of the caller's single host buffers
  * (that is the gather).  No data-path exchange between devices: instances are independent (simulateTRAN.ts:130 is one
- * circuit, one thread).  A device may be listed more than once (it then gets several shards).  opt->device is ignored.
+ * circuit, one thread).  A device may be listed more than once (it then gets several shards; shards in group mode then
+ * run one after the other on it — "Launch admission" at the top of this file).  opt->device is ignored.
  *   devices   [n_dev] HIP device ordinals, n_dev >= 1; n_dev > n_inst leaves the surplus devices idle
  * Errors: the first failing shard's status; spicey_multi_last_error names the device. */
 typedef struct SpiceyMulti SpiceyMulti;
@@ -220,6 +261,8 @@ int32_t spicey_get_state_multi(SpiceyMulti *m, double *C_vprev, double *L_iprev,
 /* Shard `shard` (0 .. n_shards-1): its SpiceyInfo, first instance and instance count; returns SPICEY_ERR_BAD_DESC past the end. */
 int32_t spicey_multi_get_shard(SpiceyMulti *m, int32_t shard, SpiceyInfo *info, int32_t *device, int32_t *first_inst, int32_t *n_inst);
 int64_t spicey_multi_last_solve_count(SpiceyMulti *m);  /* all shards */
+int32_t spicey_multi_group_retries(SpiceyMulti *m);      /* spicey_group_retries summed over the shards */
+int64_t spicey_multi_group_stale_polls(SpiceyMulti *m);  /* spicey_group_stale_polls summed over the shards */
 double spicey_multi_last_kernel_ms(SpiceyMulti *m);     /* the slowest shard's kernel */
 const char *spicey_multi_last_error(SpiceyMulti *m);    /* NULL handle -> the calling thread's last failed create */
 void spicey_destroy_multi(SpiceyMulti *m);

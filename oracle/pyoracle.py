@@ -35,6 +35,10 @@ def lib():
         L.spicey_ref_run.restype = C.c_int32
         L.spicey_ref_run.argtypes = [C.POINTER(abi.SpiceyDesc), C.c_int32, C.c_int64, C.c_double, f64p, f64p, f64p, i32p,
                                      f64p, f64p, f64p, i32p, C.POINTER(C.c_int64), i32p]
+        L.spicey_ref_set_knobs.restype = None
+        L.spicey_ref_set_knobs.argtypes = [C.c_int32, f64p]
+        L.spicey_ref_get_skips.restype = None
+        L.spicey_ref_get_skips.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.spicey_ref_timestep.restype = None
         L.spicey_ref_timestep.argtypes = [C.c_double, C.c_double, f64p, C.POINTER(C.c_int64)]
         L.spicey_ref_ac.restype = C.c_int32
@@ -48,7 +52,14 @@ def _p(a, t):
 
 
 class OracleBackend:
-    """Single-threaded reference-algorithm backend (dense GE in the reference's operation order)."""
+    """Single-threaded reference-algorithm backend (dense GE in the reference's operation order).
+
+    skip_off=True runs solveReal WITHOUT its `|f| < EPS` row-update skip (solveReal.ts:45) — a test knob, not the reference's
+    behaviour.  Every run also reports `skipped` (nonzero multipliers the reference's skip dropped, per instance),
+    `skip_solves` (solves with at least one) and `lin_err` [n_inst][steps+1] (the one-shot linearisation error per step)."""
+
+    def __init__(self, skip_off: bool = False):
+        self.skip_off = bool(skip_off)
 
     def run(self, flat: abi.FlatCircuit, steps: int, dt: float, src: np.ndarray, want_currents: bool = True,
             want_iters: bool = True) -> dict:
@@ -64,16 +75,24 @@ class OracleBackend:
               "S_ison": flat.S_ison.copy()}
         status, detail = abi.OK, ""
         es, ei = C.c_int64(0), C.c_int32(0)
+        lin_err = np.zeros((ni, steps + 1))
+        skipped, skip_solves = np.zeros(ni, np.int64), np.zeros(ni, np.int64)
         for k in range(ni):
+            L.spicey_ref_set_knobs(1 if self.skip_off else 0, _p(lin_err[k], C.c_double))
             rc = L.spicey_ref_run(C.byref(d), k, steps, dt, _p(src, C.c_double), _p(out_v[k], C.c_double),
                                   _p(out_i[k], C.c_double) if want_currents else None,
                                   _p(iters[k], C.c_int32) if want_iters else None,
                                   _p(st["C_vprev"][k], C.c_double), _p(st["L_iprev"][k], C.c_double),
                                   _p(st["D_vdprev"][k], C.c_double), _p(st["S_ison"][k], C.c_int32),
                                   C.byref(es), C.byref(ei))
+            a, b2 = C.c_int64(0), C.c_int64(0)
+            L.spicey_ref_get_skips(C.byref(a), C.byref(b2))
+            skipped[k], skip_solves[k] = a.value, b2.value
             if rc != abi.OK and status == abi.OK:
                 status, detail = rc, f"singular at inst {k} step {es.value} iter {ei.value}"
-        return {"status": status, "detail": detail, "out_v": out_v, "out_i": out_i, "iters": iters, "state": st}
+        L.spicey_ref_set_knobs(0, None)
+        return {"status": status, "detail": detail, "out_v": out_v, "out_i": out_i, "iters": iters, "state": st,
+                "skipped": skipped, "skip_solves": skip_solves, "lin_err": lin_err}
 
 
     def run_ac(self, flat: abi.FlatCircuit, freqs: np.ndarray, vph: np.ndarray, want_currents: bool = True) -> dict:

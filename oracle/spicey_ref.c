@@ -122,9 +122,23 @@ static inline void stamp_cur(double *b, int np, int nm, double cur) {
   if (im >= 0) b[im] = b[im] + cur;
 }
 
+/* Test knobs of the checker (never part of the reference's behaviour unless stated):
+ *   skip_off    1 = run solveReal WITHOUT `if (Math.abs(f) < EPS) continue` (solveReal.ts:45): the same algorithm with every
+ *               row update performed.  Used to show that the product's only semantic difference to the reference is that line.
+ *   skipped     how many NONZERO multipliers the last run skipped (exact zeros are structural and change nothing)
+ *   skip_solves how many solves of the last run skipped at least one
+ *   lin_err     if set, [steps+1] per step max over the diodes of |vd(x) - vd_lin|, vd_lin = the junction voltage the step's
+ *               last solve was stamped with (simulateTRAN.ts:81-85) */
+static int g_skip_off = 0;
+static int64_t g_skipped = 0, g_skip_solves = 0;
+static double *g_lin_err = 0;
+void spicey_ref_set_knobs(int32_t skip_off, double *lin_err) { g_skip_off = skip_off; g_lin_err = lin_err; }
+void spicey_ref_get_skips(int64_t *skipped, int64_t *skip_solves) { if (skipped) *skipped = g_skipped; if (skip_solves) *skip_solves = g_skip_solves; }
+
 /* solveReal.ts:3-73; rows[] are pointers into an (n x (n+1)) slab, augmented column = b.
  * Returns 0, or 1 for "Singular matrix (real)". */
 static int solve_real(double **rows, int n, double *x) {
+  int64_t skipped_here = 0;
   for (int k = 0; k < n; k++) {
     int imax = k;
     double vmax = fabs(rows[k][k]);
@@ -146,10 +160,15 @@ static int solve_real(double **rows, int n, double *x) {
     for (int i = k + 1; i < n; i++) {
       double *row = rows[i];
       double f = row[k] / pivot;
-      if (fabs(f) < EPS) continue;
+      if (fabs(f) < EPS) {
+        if (f != 0.0) skipped_here++;
+        if (!g_skip_off || f == 0.0) continue;
+      }
       for (int j = k; j <= n; j++) row[j] = row[j] - f * prow[j];
     }
   }
+  g_skipped += skipped_here;
+  g_skip_solves += skipped_here > 0;
   for (int i = n - 1; i >= 0; i--) {
     const double *row = rows[i];
     double s = row[n];
@@ -196,7 +215,9 @@ int32_t spicey_ref_run(const SpiceyDesc *d, int32_t inst, int64_t steps, double 
   double **rows = (double **)malloc((size_t)(n > 0 ? n : 1) * sizeof(double *));
   double *b = (double *)malloc((size_t)(n + 1) * sizeof(double));
   double *x = (double *)malloc((size_t)(n + 1) * sizeof(double));
+  double *vdlin = (double *)malloc((size_t)(nD + 1) * sizeof(double));
   int32_t rc = SPICEY_OK;
+  g_skipped = 0; g_skip_solves = 0;
 
 #define VOLT(node) ((node) == 0 ? 0.0 : x[(node)-1])
   for (int64_t step = 0; step <= steps && rc == SPICEY_OK; step++) {
@@ -240,6 +261,7 @@ int32_t spicey_ref_run(const SpiceyDesc *d, int32_t inst, int64_t steps, double 
         int np = d->D_np[i], nm = d->D_nm[i];
         double vd_iter = VOLT(np) - VOLT(nm);
         double vd = iter == 0 ? vdprev[i] : vd_iter;
+        vdlin[i] = vd;
         double vt = Dn[i] * VT_300K;
         double vl = vd;
         if (vd > 0.8) vl = 0.8;
@@ -280,6 +302,14 @@ int32_t spicey_ref_run(const SpiceyDesc *d, int32_t inst, int64_t steps, double 
     }
     if (rc != SPICEY_OK) break;
     if (iters) iters[step] = iter + 1;
+    if (g_lin_err) {
+      double m = 0.0;
+      for (int i = 0; i < nD; i++) {
+        double e = fabs((VOLT(d->D_np[i]) - VOLT(d->D_nm[i])) - vdlin[i]);
+        if (e > m) m = e;
+      }
+      g_lin_err[step] = m;
+    }
 
     /* record node voltages :164-171 */
     if (out_v) {
@@ -327,7 +357,7 @@ int32_t spicey_ref_run(const SpiceyDesc *d, int32_t inst, int64_t steps, double 
   if (D_vdprev) memcpy(D_vdprev, vdprev, sizeof(double) * nD);
   if (S_ison) memcpy(S_ison, ison, sizeof(int32_t) * nS);
   free(vprev); free(iprev); free(vdprev); free(ison);
-  free(slab); free(rows); free(b); free(x);
+  free(slab); free(rows); free(b); free(x); free(vdlin);
   return rc;
 }
 

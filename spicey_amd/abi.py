@@ -13,7 +13,7 @@ import numpy as np
 
 from .netlist import EPS, ParsedCircuit
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, ERR_SINGULAR, ERR_BAD_DESC, ERR_HIP, ERR_NO_DEVICE, ERR_COMPLEX_DIV = 0, 1, 2, 3, 4, 5
 
 _I32P = C.POINTER(C.c_int32)
@@ -37,7 +37,8 @@ class SpiceyDesc(C.Structure):
 
 class SpiceyOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("threads", C.c_int32), ("inst_per_wg", C.c_int32),
-                ("want_currents", C.c_int32), ("force_global", C.c_int32), ("profile", C.c_int32), ("interpreter", C.c_int32), ("geometry", C.c_int32), ("debug", C.c_int32), ("wgs_per_inst", C.c_int32), ("front_cut", C.c_int32)]
+                ("want_currents", C.c_int32), ("force_global", C.c_int32), ("profile", C.c_int32), ("interpreter", C.c_int32), ("geometry", C.c_int32), ("debug", C.c_int32), ("wgs_per_inst", C.c_int32), ("front_cut", C.c_int32),
+                ("group_retry", C.c_int32), ("group_timeout_ms", C.c_int32), ("diagnostics", C.c_int32)]
 
 
 class SpiceyInfo(C.Structure):

@@ -241,9 +241,11 @@ SPICEY_HD void spicey_ac_dense_solve(Exec &ex, const SpiceyProg &P, const Spicey
     if (imax != k)
       ex.phase(SPICEY_PH_U0, [&](int tid) {
         for (int j = tid; j <= n; j += T) {
-          const SpiceyCx a = A[(size_t)k * ld + (size_t)j];
-          A[(size_t)k * ld + (size_t)j] = A[(size_t)imax * ld + (size_t)j];
-          A[(size_t)imax * ld + (size_t)j] = a;
+          // (field by field: a struct temporary here becomes a 16-byte memcpy through a stack slot, i.e. a scratch frame)
+          SpiceyCx *pk = A + (size_t)k * ld + (size_t)j, *pi = A + (size_t)imax * ld + (size_t)j;
+          const double kr = pk->re, ki = pk->im, ir = pi->re, ii = pi->im;
+          pk->re = ir; pk->im = ii;
+          pi->re = kr; pi->im = ki;
         }
       });
     ex.phase(SPICEY_PH_U0, [&](int tid) {

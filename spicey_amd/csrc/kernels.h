@@ -5,7 +5,7 @@
 
 #include "program.h"
 
-#define SPICEY_GRP_SYNC_WORDS 320  // uint32 words of barrier state per group: [0] flat counter, [1] abort, [16..] XCD census / arrivals / top / generation
+#define SPICEY_GRP_SYNC_WORDS 320  // uint32 words of barrier state per group: [0] flat counter, [1] abort, [2..7] timeout note, [8] stale polls, [16..] XCD census / arrivals / top / generation
 #define SPICEY_LDS_MAX 163840  // 160 KiB per CU on MI355X (MI355X_MICROARCH.md "Chip-level parameters")
 
 size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds, int tail_n = 0);
@@ -24,3 +24,4 @@ hipError_t spicey_launch_tran_v2(const SpiceyProg &Ph, const SpiceyResident &Qh,
 
 // group mode: R.wgs_per_group workgroups per K instances, workspace in global memory (large circuits)
 hipError_t spicey_launch_tran_grp(const SpiceyProg &P, const SpiceyRun &R, int K, int n_groups, int threads, hipStream_t st);
+int spicey_grp_blocks_per_cu(const SpiceyProg &P, int K, int threads);  // occupancy of that kernel (0: cannot run)

@@ -165,17 +165,56 @@ struct GpuGroupExec {
   }
   template <class F>
   __device__ __forceinline__ void wave_lockstep(int nlanes, int nsteps, F f) { gpu_wave_lockstep(nlanes, nsteps, f); }
-  // front hand-off between two workgroups of the group: the producer's stores are drained by every wave, the workgroup
-  // meets, lane 0 releases at agent scope and publishes the solve number; the consumer polls relaxed, acquires, and
-  // holds its workgroup's barrier until the invalidate has completed (MI355X_MICROARCH.md, valid forms)
-  // the first workgroup whose spin runs out leaves a note for the host's error text: counter[2..7] = {kind (1 group barrier,
-  // 2 front hand-over, 3 census barrier), workgroup, barrier number / front flag index, value waited for, value seen, XCD}
+  // the first workgroup whose wait runs out leaves a note for the host's error text: counter[2..7] = {kind (1 group barrier,
+  // 2 front hand-over, 3 census barrier, 4 census does not add up), workgroup, barrier number / front flag index, value
+  // waited for, value seen, XCD}; counter[8] counts waits that only a read-modify-write poll saw satisfied (below)
   __device__ __forceinline__ void note_timeout(unsigned int kind, unsigned int what, unsigned int want, unsigned int seen) {
     if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u &&
         __hip_atomic_exchange(counter + 2, kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
       counter[3] = (unsigned int)wgi; counter[4] = what; counter[5] = want; counter[6] = seen; counter[7] = my_x;
     }
   }
+  // ONE lane waits until *word has reached `want` (wrap-safe signed distance).  Every wait is bounded in TIME: `limit` ticks
+  // of the chip-wide 100 MHz counter (SpiceyRun::grp_timeout_ticks; the clock is looked at every 1024 polls, the first time
+  // ~0.4 ms into the wait, which starts the measurement).  At the same cadence the word is also read by an atomic
+  // read-modify-write (+0), which is served at the memory side and cannot return a stale cached line: should the plain
+  // `sc1` poll ever fail to see a value that is there, the wait ends at the next such read and counter[8] counts it
+  // (spicey_group_stale_polls) instead of running into the deadline.  Returns false when the launch is aborting.
+  unsigned long long limit;
+  __device__ __forceinline__ bool spin_until(unsigned int *word, unsigned int want, unsigned int kind, unsigned int what) {
+    unsigned int spins = 0;
+    unsigned long long t0 = 0;
+    for (;;) {
+      unsigned int v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)(v - want) >= 0) return true;
+      if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+      if ((++spins & 1023u) == 0u) {
+        v = __hip_atomic_fetch_add(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - want) >= 0) {
+          __hip_atomic_fetch_add(counter + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return true;
+        }
+        const unsigned long long now = (unsigned long long)wall_clock64();
+        if (t0 == 0) t0 = now;
+        else if (now - t0 > limit) {
+          note_timeout(kind, what, want, v);
+          __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return false;
+        }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  // what lane 0 learned about the abort word reaches every wave through one LDS word, so that `bad` — and with it every
+  // branch on failed() — is uniform across the workgroup (each lane reading the abort word for itself could see the moment
+  // it is raised differently)
+  unsigned int *s_ab;
+  __device__ __forceinline__ void publish_abort() {  // lane 0, before the workgroup barrier that ends a wait
+    *s_ab = __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // front hand-off between two workgroups of the group: the producer's stores are drained by every wave, the workgroup
+  // meets, lane 0 releases at agent scope and publishes the solve number; the consumer polls relaxed, acquires, and
+  // holds its workgroup's barrier until the invalidate has completed (MI355X_MICROARCH.md, valid forms)
   __device__ __forceinline__ void front_post(unsigned int *flag, unsigned int value) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -187,21 +226,15 @@ struct GpuGroupExec {
   }
   __device__ __forceinline__ void front_wait(unsigned int *flag, unsigned int value) {
     if (threadIdx.x == 0) {
-      unsigned int spins = 0;
-      while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
-        if (++spins > (1u << 22) || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          if (spins > (1u << 22)) note_timeout(2u, (unsigned int)(flag - counter), value, __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
+      (void)spin_until(flag, value, 2u, (unsigned int)(flag - front_flags0));
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      publish_abort();
     }
     __syncthreads();
-    if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) bad = true;
+    if (*s_ab != 0u) bad = true;
   }
+  unsigned int *front_flags0;  // this group's first front flag (error text: which flag a hand-over waited for)
   __device__ __forceinline__ int threads() const { return G * (int)blockDim.x; }
   __device__ __forceinline__ bool failed() const { return bad; }
   __device__ __forceinline__ bool serial_chain() const { return G > 1; }
@@ -232,14 +265,26 @@ struct GpuGroupExec {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(hb + my_x * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     flat_barrier();
     n_mine = 0; n_xcd = 0;
+    unsigned int total = 0;
     for (unsigned int i = 0; i < 8; i++) {
       const unsigned int m = __hip_atomic_load(hb + i * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       n_xcd += m != 0u ? 1u : 0u;
+      total += m;
       if (i == my_x) n_mine = m;
     }
     n_mine = (unsigned int)__builtin_amdgcn_readfirstlane((int)n_mine);
     n_xcd = (unsigned int)__builtin_amdgcn_readfirstlane((int)n_xcd);
+    total = (unsigned int)__builtin_amdgcn_readfirstlane((int)total);
     hep = 0;
+    // every later barrier counts on these numbers: a census that does not add up to G (a workgroup that read the member
+    // counts before all of them had landed) would leave a barrier one arrival short for ever — refuse to run on it
+    if (total != (unsigned int)G || n_mine == 0u) {
+      if (threadIdx.x == 0 && !bad) {
+        note_timeout(4u, total, (unsigned int)G, n_mine);
+        __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      bad = true;
+    }
   }
   __device__ __forceinline__ void barrier() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -253,20 +298,13 @@ struct GpuGroupExec {
         const unsigned int t = __hip_atomic_fetch_add(hb + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t + 1u == hep * n_xcd) __hip_atomic_store(hb + 272, hep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      unsigned int spins = 0;
-      while ((int)(__hip_atomic_load(hb + 272, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - hep) < 0) {
-        if (++spins > (1u << 22) || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          if (spins > (1u << 22)) note_timeout(1u, hep, __hip_atomic_load(hb + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(hb + 128 + my_x * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
+      (void)spin_until(hb + 272, hep, 1u, hep);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      publish_abort();
     }
     __syncthreads();
-    if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) bad = true;
+    if (*s_ab != 0u) bad = true;
   }
   // the flat form (one counter, every workgroup releases): used once, for the census
   __device__ __forceinline__ void flat_barrier() {
@@ -277,21 +315,13 @@ struct GpuGroupExec {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned int target = epoch * (unsigned int)G;
-      unsigned int spins = 0;
-      while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (++spins > (1u << 22) || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          if (spins > (1u << 22)) note_timeout(3u, epoch, target, __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
+      (void)spin_until(counter, epoch * (unsigned int)G, 3u, epoch);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      publish_abort();
     }
     __syncthreads();
-    if (__hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) bad = true;
+    if (*s_ab != 0u) bad = true;
   }
   // thread ids of a group phase: wave v of workgroup g is wave v * G + g of the group, so that consecutive slices of a
   // task list (sorted longest first) go to different workgroups
@@ -337,8 +367,20 @@ __global__ void __launch_bounds__(FRONTS ? 512 : 1024) spicey_tran_kernel_grp(Sp
     c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
   }
   unsigned int *gs = R.grp_sync + (size_t)grp * SPICEY_GRP_SYNC_WORDS;
-  GpuGroupExec ex{G, wgi, gs, gs + 1, 0u, false, (double *)smem,
-                  R.prof ? R.prof + (size_t)blockIdx.x * SPICEY_PH_SLOTS : nullptr, (unsigned long long)wall_clock64(), gs + 16, 0u, 0u, 1u, 1u};
+  __shared__ unsigned int s_abort;  // lane 0's view of the abort word, for the whole workgroup (GpuGroupExec::publish_abort)
+  GpuGroupExec ex;
+  ex.G = G; ex.wgi = wgi;
+  ex.counter = gs; ex.abortf = gs + 1;
+  ex.epoch = 0u; ex.bad = false;
+  ex.lds_ = (double *)smem;
+  ex.prof = R.prof ? R.prof + (size_t)blockIdx.x * SPICEY_PH_SLOTS : nullptr;
+  ex.last = (unsigned long long)wall_clock64();
+  ex.limit = R.grp_timeout_ticks;
+  ex.s_ab = &s_abort;
+  ex.front_flags0 = R.front_flags ? R.front_flags + (size_t)grp * 2 * (size_t)P.nFronts : gs;
+  ex.hb = gs + 16; ex.hep = 0u; ex.my_x = 0u; ex.n_mine = 1u; ex.n_xcd = 1u;
+  if (threadIdx.x == 0) s_abort = 0u;
+  __syncthreads();
   ex.census();
   if (R.force_abort && wgi == 0 && threadIdx.x == 0) __hip_atomic_store(gs + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (tests)
   spicey_tran_run<K, FRONTS>(ex, P, R, c, grp);
@@ -516,26 +558,41 @@ size_t spicey_gw_doubles_per_wg(const SpiceyProg &P, int K) {
 }
 
 template <int K, bool FRONTS>
-static hipError_t launch_grp_t(const SpiceyProg &P, const SpiceyRun &R, int grid, int threads, size_t lds, hipStream_t st) {
+static hipError_t launch_grp_t(const SpiceyProg &P, const SpiceyRun &R, int grid, int threads, size_t lds, hipStream_t st, int *blocks_per_cu = nullptr) {
   auto kern = spicey_tran_kernel_grp<K, FRONTS>;
   if (FRONTS && threads > 512) return hipErrorInvalidValue;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
+  if (blocks_per_cu)  // residency query only (spicey_grp_blocks_per_cu)
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(kern), threads, lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, P, R);
   return hipGetLastError();
 }
 
-hipError_t spicey_launch_tran_grp(const SpiceyProg &P, const SpiceyRun &R, int K, int n_groups, int threads, hipStream_t st) {
-  const int grid = n_groups * R.wgs_per_group;
+static hipError_t grp_dispatch(const SpiceyProg &P, const SpiceyRun &R, int K, int grid, int threads, hipStream_t st, int *blocks_per_cu) {
   const size_t lds = spicey_front_lds_bytes(P);
-  if (P.nFronts > 0) return K == 1 ? launch_grp_t<1, true>(P, R, grid, threads, lds, st) : hipErrorInvalidValue;
+  if (P.nFronts > 0) return K == 1 ? launch_grp_t<1, true>(P, R, grid, threads, lds, st, blocks_per_cu) : hipErrorInvalidValue;
   switch (K) {
-    case 1: return launch_grp_t<1, false>(P, R, grid, threads, 0, st);
-    case 2: return launch_grp_t<2, false>(P, R, grid, threads, 0, st);
+    case 1: return launch_grp_t<1, false>(P, R, grid, threads, 0, st, blocks_per_cu);
+    case 2: return launch_grp_t<2, false>(P, R, grid, threads, 0, st, blocks_per_cu);
   }
   return hipErrorInvalidValue;
+}
+
+hipError_t spicey_launch_tran_grp(const SpiceyProg &P, const SpiceyRun &R, int K, int n_groups, int threads, hipStream_t st) {
+  return grp_dispatch(P, R, K, n_groups * R.wgs_per_group, threads, st, nullptr);
+}
+
+// Workgroups of the group-mode kernel for this program that one CU can hold at `threads` threads (the runtime's answer for
+// the very kernel and LDS size that will be launched); the host sizes a group so that grid * G workgroups fit the chip at
+// ONE per CU and refuses to run when the answer is 0.
+int spicey_grp_blocks_per_cu(const SpiceyProg &P, int K, int threads) {
+  int nb = 0;
+  SpiceyRun none{};
+  if (grp_dispatch(P, none, K, 1, threads, nullptr, &nb) != hipSuccess) return 0;
+  return nb;
 }
 
 hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bool lds, int grid, int threads, hipStream_t st) {
@@ -564,15 +621,18 @@ hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bo
 // NO variant spills: ROCm 7.2's hipcc places spill stores of values defined in divergent loops where EXEC can
 // be zero (the store is lost and a later reload returns a previous kernel's scratch) — observed as stale vPrev
 // registers; the Makefile therefore fails the build if any kernel reports a non-zero ScratchSize.
-//   T <= 256 : 32 slots, 12 entries, 4 elements per thread (one wave per SIMD: up to 512 VGPRs; K = 1 or 2)
-//   T <= 512 : 16 slots,  8 entries, 2 elements per thread (<= 256 VGPRs; K = 1 only)
-//   T <= 1024:  8 slots,  4 entries, 1 element  per thread (<= 128 VGPRs; K = 1 only)
+//   T <= 256 : 28 slots, 12 entries, 4 elements per thread (one wave per SIMD, 256 VGPRs, no spills to AGPRs)
+//   (K = 2 interleaved instances: every variant tried — 16 to 32 slots — spilled 9 vector registers to AGPRs; the 16-bit
+//   interpreter is therefore built for K = 1 only and interleaved instances run on interpreter 1)
+//   T <= 512 : 16 slots,  8 entries, 2 elements per thread (<= 256 VGPRs)
+//   T <= 1024:  8 slots,  4 entries, 1 element  per thread (<= 128 VGPRs)
 // `packed` = the two-workgroups-per-CU geometry: 512 threads, <= 128 VGPRs; only 4 slots stay resident (the small,
 // latency-critical phases), the wide bottom levels are streamed from L2 with the records prefetched in batches.
-int spicey_v2_rmax(int threads, bool packed) { return packed ? 4 : (threads <= 256 ? 32 : (threads <= 512 ? 16 : 8)); }
+#define SPICEY_V2_RMAX256 28  // (32 slots spilled 6 vector registers to AGPRs: refused by check_no_spills.py)
+int spicey_v2_rmax(int threads, bool packed) { return packed ? 4 : (threads <= 256 ? SPICEY_V2_RMAX256 : (threads <= 512 ? 16 : 8)); }
 int spicey_v2_nsv(int threads, bool packed) { return packed ? 6 : (threads <= 256 ? 12 : (threads <= 512 ? 8 : 4)); }
 int spicey_v2_nel(int threads, bool packed) { return packed ? 2 : (threads <= 256 ? 4 : (threads <= 512 ? 2 : 1)); }
-int spicey_v2_max_threads(int K) { return K == 1 ? 1024 : 256; }
+int spicey_v2_max_threads(int K) { return K == 1 ? 1024 : 0; }
 
 hipError_t spicey_launch_tran_v2(const SpiceyProg &Ph, const SpiceyResident &Qh, const SpiceyProg *P, const SpiceyResident *Q, const SpiceyRun *R, int K, int grid,
                                  int threads, hipStream_t st, bool packed) {
@@ -582,10 +642,7 @@ hipError_t spicey_launch_tran_v2(const SpiceyProg &Ph, const SpiceyResident &Qh,
     return hipErrorInvalidValue;
   }
   if (threads <= 256) {
-    switch (K) {
-      case 1: return launch_v2_t<1, 32, 12, 4, 256, 1>(P, Q, R, grid, threads, bytes, st);
-      case 2: return launch_v2_t<2, 32, 12, 4, 256, 1>(P, Q, R, grid, threads, bytes, st);
-    }
+    if (K == 1) return launch_v2_t<1, SPICEY_V2_RMAX256, 12, 4, 256, 1>(P, Q, R, grid, threads, bytes, st);
   } else if (threads <= 512) {
     if (K == 1) return launch_v2_t<1, 16, 8, 2, 512, 2>(P, Q, R, grid, threads, bytes, st);
   } else if (K == 1) {

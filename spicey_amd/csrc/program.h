@@ -173,6 +173,11 @@ struct SpiceyProg {
   const int32_t *ent_ro, *ent_co;   // [nLU]
   const int32_t *pos_row, *pos_col; // [n]
 
+  // --- diagnostics (SpiceyOptions.diagnostics bit 0): the structural entries of A column by column in the reference's
+  //     numbering — col_ent[col_ptr[c] .. col_ptr[c + 1]) = entry id, | SPICEY_TGT_RECIP where the workspace holds the
+  //     entry's reciprocal after phase B (leaf diagonals).  Fill entries (zero in A) are not listed.
+  const uint32_t *col_ptr, *col_ent;  // [n + 1], [nnzA]
+
   // --- elements: terminal positions in W (x' slots), -1 = ground
   const int32_t *R_a, *R_b, *C_a, *C_b, *L_a, *L_b, *S_a, *S_b, *S_cp, *S_cn, *D_a, *D_b;
   const int32_t *V_x;   // [nV] W index of the branch current
@@ -234,8 +239,8 @@ struct SpiceyRun {
   // status: [n_workgroups][4] = {code, inst, step, iter}; solve counts [n_workgroups]
   int32_t *status;
   unsigned long long *solves;
-  // multi-workgroup-per-instance mode (large circuits): [n_groups][4] = {barrier counter, abort flag, -, -}, zeroed
-  // before every launch, and [n_groups][4] int32 flags (the WgCtx flags live in global memory there)
+  // multi-workgroup-per-instance mode (large circuits): [n_groups][SPICEY_GRP_SYNC_WORDS] = {flat counter, abort flag, timeout note [2..7],
+  // stale-poll count [8], -, XCD census / arrivals / top / generation [16..]}, zeroed before every launch, and [n_groups][4] int32 flags (the WgCtx flags live in global memory there)
   unsigned int *grp_sync;
   int32_t *grp_flags;
   int32_t wgs_per_group;
@@ -247,7 +252,18 @@ struct SpiceyRun {
   unsigned int *front_flags;
   int32_t front_lds_doubles;  // LDS scratch per workgroup (fronts that fit live there whole; tests shrink it to force the staged path)
   int32_t force_abort;        // tests: group mode raises its abort word at start-up (exercises the host's one relaunch)
+  // group mode: longest single cross-workgroup wait, in ticks of the chip-wide 100 MHz counter, before the launch aborts
+  unsigned long long grp_timeout_ticks;
   // profiling: per front {forward: children assembled, forward: done; backward: parent's unknowns there, backward: done},
   // 100 MHz ticks since the owner entered the forward sweep of that solve, summed over the solves [n_groups][nFronts][4]
   unsigned long long *front_ticks;
+  // diagnostics (null = off; none of them feeds back into the solve)
+  //   skip_risk [n_inst]: (solve, column) pairs whose stamped matrix column holds a nonzero entry below 1e-15 x the column's
+  //     largest — where the reference's partial pivoting makes `|f| < EPS` (solveReal.ts:45) drop a row update this build performs
+  //   lin_vd [n_inst][nD]: junction voltage every diode was linearised at for the solve in progress (simulateTRAN.ts:85);
+  //   lin_err [n_inst][steps+1]: max over the diodes of |vd(x) - lin_vd| after the step's last solve, as the bit pattern of a
+  //     non-negative double (combined with integer atomic max; zeroed by the host before the launch)
+  unsigned long long *skip_risk;
+  double *lin_vd;
+  unsigned long long *lin_err;
 };

@@ -6,8 +6,11 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -55,6 +58,14 @@ struct SpiceyHandle {
   int32_t *d_Son_s = nullptr;
   SpiceyRun grp_R{};      // that launch's arguments
   int group_retries = 0;  // launches repeated so far (spicey_group_retries)
+  // diagnostics (SpiceyOptions.diagnostics): skip-risk counters [n_inst], linearisation points [n_inst][nD], per-step
+  // linearisation error [n_inst][steps + 1] of the last run (grown on demand)
+  unsigned long long *d_skip = nullptr, *d_linerr = nullptr;
+  double *d_linvd = nullptr;
+  size_t linerr_cap = 0;
+  int64_t last_steps = -1;
+  int64_t stale_polls = 0;  // group mode: waits that only the read-modify-write poll saw satisfied (spicey_group_stale_polls)
+  bool gated = false;     // this handle is counted in its device's group-mode handles (DeviceGate)
   int32_t *d_Son0 = nullptr;
   double *d_gstat = nullptr, *d_statv = nullptr, *d_rcoef = nullptr, *d_gW = nullptr, *d_dpar = nullptr;
   int32_t *d_status = nullptr;
@@ -96,6 +107,70 @@ struct Roctx {
 };
 }  // namespace
 
+// ---- launch admission per device (include/spicey_hip.h, "Launch admission") ------------------------------------------
+// A group-mode launch (G > 1 workgroups per instance that wait for one another inside the kernel) needs all its workgroups
+// resident.  The host sizes it to at most one workgroup per CU, so that holds on an otherwise idle device; what must not
+// happen is a second launch of this library taking CUs away while the group is starting, or two groups each holding some
+// CUs and waiting for the rest.  Per device: `ev_group` = completion of the last group-mode launch; `ring` = completions of
+// the recent launches that are not group-mode.  A group-mode launch first makes its stream wait for ev_group and for every
+// ring event; any other launch waits for ev_group only (and for the ring slot it is about to reuse, which keeps "waiting
+// for the ring" = "waiting for every earlier launch" when more than RING launches are in flight).  All of it is
+// stream-ordered (hipStreamWaitEvent): nothing blocks on the host, so one thread may hold several launches in flight.
+// The bookkeeping is skipped while no group-mode handle exists on the device; the first one to be created drains the
+// device once (hipDeviceSynchronize) so that earlier, unrecorded launches are known to have finished.
+namespace {
+struct DeviceGate {
+  static const int RING = 16;
+  std::mutex mu;
+  int group_handles = 0;
+  hipEvent_t ev_group = nullptr;
+  bool group_recorded = false;
+  hipEvent_t ring[RING] = {};
+  bool ring_used[RING] = {};
+  int ring_next = 0;
+};
+DeviceGate &device_gate(int device) {
+  static std::mutex m;
+  static std::map<int, DeviceGate *> gates;  // (never freed: a gate may be touched by a handle destroyed at process exit)
+  std::lock_guard<std::mutex> lk(m);
+  DeviceGate *&g = gates[device];
+  if (!g) g = new DeviceGate();
+  return *g;
+}
+// with g.mu held and the device current; `st` is the launch stream.  Returns a HIP error or hipSuccess.
+hipError_t gate_before_launch(DeviceGate &g, bool group, hipStream_t st, int *slot) {
+  *slot = -1;
+  if (!group && g.group_handles == 0) return hipSuccess;
+  hipError_t e;
+  if (g.group_recorded && (e = hipStreamWaitEvent(st, g.ev_group, 0)) != hipSuccess) return e;
+  if (group) {
+    for (int i = 0; i < DeviceGate::RING; i++)
+      if (g.ring_used[i] && (e = hipStreamWaitEvent(st, g.ring[i], 0)) != hipSuccess) return e;
+    return hipSuccess;
+  }
+  const int i = g.ring_next;
+  if (!g.ring[i] && (e = hipEventCreateWithFlags(&g.ring[i], hipEventDisableTiming)) != hipSuccess) return e;
+  if (g.ring_used[i] && (e = hipStreamWaitEvent(st, g.ring[i], 0)) != hipSuccess) return e;
+  *slot = i;
+  return hipSuccess;
+}
+hipError_t gate_after_launch(DeviceGate &g, bool group, hipStream_t st, int slot) {
+  hipError_t e;
+  if (group) {
+    if (!g.ev_group && (e = hipEventCreateWithFlags(&g.ev_group, hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventRecord(g.ev_group, st)) != hipSuccess) return e;
+    g.group_recorded = true;
+    for (int i = 0; i < DeviceGate::RING; i++) g.ring_used[i] = false;  // (this launch waited for all of them)
+    return hipSuccess;
+  }
+  if (slot < 0) return hipSuccess;
+  if ((e = hipEventRecord(g.ring[slot], st)) != hipSuccess) return e;
+  g.ring_used[slot] = true;
+  g.ring_next = (slot + 1) % DeviceGate::RING;
+  return hipSuccess;
+}
+}  // namespace
+
 #define HIPCHK(h, call)                                                                 \
   do {                                                                                  \
     hipError_t e__ = (call);                                                            \
@@ -122,8 +197,13 @@ extern "C" const char *spicey_last_error(SpiceyHandle *h) { return h ? h->err.c_
 extern "C" void spicey_destroy(SpiceyHandle *h) {
   if (!h) return;
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
+  if (h->gated) {
+    DeviceGate &g = device_gate(h->device);
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.group_handles--;
+  }
   void *ptrs[] = {h->d_res, h->d_blob, h->d_R, h->d_C, h->d_L, h->d_Sron, h->d_Sroff, h->d_Svon, h->d_Svoff, h->d_Dis, h->d_Dn, h->d_Cv,
-                  h->d_Li, h->d_Dv, h->d_Son, h->d_Cv0, h->d_Li0, h->d_Dv0, h->d_Son0, h->d_Cv_s, h->d_Li_s, h->d_Dv_s, h->d_Son_s, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_Pstruct, h->d_Qstruct, h->d_Rstruct, h->d_gsync, h->d_gflags, h->d_front_ws, h->d_fs, h->d_front_flags, h->d_status, h->d_solves, h->d_prof};
+                  h->d_Li, h->d_Dv, h->d_Son, h->d_Cv0, h->d_Li0, h->d_Dv0, h->d_Son0, h->d_Cv_s, h->d_Li_s, h->d_Dv_s, h->d_Son_s, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_Pstruct, h->d_Qstruct, h->d_Rstruct, h->d_gsync, h->d_gflags, h->d_front_ws, h->d_fs, h->d_front_flags, h->d_status, h->d_solves, h->d_prof, h->d_skip, h->d_linerr, h->d_linvd};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -208,6 +288,10 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   int K = h->opt.inst_per_wg;
   const bool want_lds = !h->opt.force_global;
   if (K != 0 && K != 1 && K != 2 && K != 4) { h->err = "inst_per_wg must be 0, 1, 2 or 4"; return fail(SPICEY_ERR_BAD_DESC); }
+  // diagnostics are compiled into the kernels with at most two interleaved instances and not into the two-workgroups-per-CU
+  // geometry (tran_exec.h, DIAG): a handle with the option stays out of both
+  const bool diag = h->opt.diagnostics != 0;
+  if (diag && (K == 4 || h->opt.geometry == 2)) { h->err = "diagnostics need inst_per_wg <= 2 and geometry != 2"; return fail(SPICEY_ERR_BAD_DESC); }
   if (P.nS > 0) K = 1;  // the switch iteration count is per instance: no interleaving
   if (P.nFronts > 0) K = 1;  // dense fronts: one instance per workgroup (group)
   if (K == 0) {
@@ -215,7 +299,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
     // Global-workspace path (large circuits): once the batch exceeds the CUs, interleaving 2-4 instances shares
     // the index stream and fills more of every gathered cache line (rcd_mesh(50) x 1024: ~3x with K = 4).
     K = 1;
-    if (!want_lds || spicey_lds_bytes(P, 1, true) > SPICEY_LDS_MAX) K = h->n_inst >= 4 * ncu ? 4 : (h->n_inst >= 2 * ncu ? 2 : 1);
+    if (!want_lds || spicey_lds_bytes(P, 1, true) > SPICEY_LDS_MAX) K = (h->n_inst >= 4 * ncu && !diag) ? 4 : (h->n_inst >= 2 * ncu ? 2 : 1);
   }
   if (K > h->n_inst) K = 1;
   h->lds = want_lds && spicey_lds_bytes(P, K, true) <= SPICEY_LDS_MAX;
@@ -224,16 +308,16 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
     h->lds = true;
   }
   h->K = K;
-  // interpreter: v2 needs the LDS workspace, 16-bit records and K <= 2
-  const bool v2_ok = h->lds && P.has16 && K <= 2;
-  if (h->opt.interpreter == 2 && !v2_ok) { h->err = "interpreter 2 needs the LDS workspace, < 65536 workspace entries and inst_per_wg <= 2"; return fail(SPICEY_ERR_BAD_DESC); }
+  // interpreter: v2 needs the LDS workspace, 16-bit records and one instance per workgroup (the K = 2 build of the
+  // register-resident kernel spilled vector registers whatever its geometry: kernels.hip)
+  const bool v2_ok = h->lds && P.has16 && K == 1;
+  if (h->opt.interpreter == 2 && !v2_ok) { h->err = "interpreter 2 needs the LDS workspace, < 65536 workspace entries and inst_per_wg = 1"; return fail(SPICEY_ERR_BAD_DESC); }
   h->interp = (h->opt.interpreter == 1 || !v2_ok) ? 1 : 2;
   h->T = h->opt.threads > 0 ? h->opt.threads : pick_threads(h->hp, h->interp == 2, K);
   if (P.nFronts > 0 && h->T > 512) {  // kernels with the dense-front code are built for <= 512 threads (256 VGPRs)
     if (h->opt.threads > 512) { h->err = "front_cut needs threads <= 512"; return fail(SPICEY_ERR_BAD_DESC); }
     h->T = 512;
   }
-  if (h->interp == 2 && h->T > spicey_v2_max_threads(K)) { h->err = "interpreter 2 with inst_per_wg = 2 supports at most 256 threads"; return fail(SPICEY_ERR_BAD_DESC); }
   if (h->T > 1024 || (h->T & 63) || h->T < 64) { h->err = "threads must be a multiple of 64 in [64, 1024]"; return fail(SPICEY_ERR_BAD_DESC); }
   h->grid = (h->n_inst + K - 1) / K;
   h->lds_bytes = spicey_lds_bytes(P, K, h->lds);
@@ -246,7 +330,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
                           P.nRestore <= spicey_v2_nsv(512, true) * 512 && (h->opt.threads == 0 || h->opt.threads == 512);
     if (h->opt.geometry == 2 && !packable) { h->err = "geometry 2 needs inst_per_wg = 1, <= 80 KB of LDS per instance and <= 1024 unknowns"; return fail(SPICEY_ERR_BAD_DESC); }
     if (h->opt.geometry < 0 || h->opt.geometry > 2) { h->err = "geometry must be 0, 1 or 2"; return fail(SPICEY_ERR_BAD_DESC); }
-    h->packed = packable && (h->opt.geometry == 2 || (h->opt.geometry == 0 && h->n_inst >= 2 * ncu && h->opt.threads == 0));
+    h->packed = packable && !diag && (h->opt.geometry == 2 || (h->opt.geometry == 0 && h->n_inst >= 2 * ncu && h->opt.threads == 0));
     if (h->packed) { h->T = 512; h->grid = (h->n_inst + K - 1) / K; }
     // tail levels go to LDS: as many as fit beside the workspace (1 KB each), at most 24; the packed geometry
     // must leave room for a second workgroup on the CU
@@ -323,8 +407,24 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
         while (G * 2 <= gmax && h->grid * G * 2 <= ncu) G *= 2;
     }
     if (h->grid * G > ncu) G = std::max(1, ncu / h->grid);
+    if (G > 1) {
+      // residency: ask the runtime how many workgroups of THIS kernel (its LDS size, these threads) a CU holds; the group
+      // is laid out for one per CU, so any answer >= 1 means grid * G <= #CU workgroups are co-resident on an idle device
+      const int T_grp = (P.nFronts > 0 && h->T > 512) ? 512 : h->T;
+      if (spicey_grp_blocks_per_cu(P, K, T_grp) < 1) {
+        if (h->opt.wgs_per_inst > 1) { h->err = "wgs_per_inst: the group-mode kernel cannot be resident on this device (occupancy query says 0 workgroups per CU)"; return fail(SPICEY_ERR_HIP); }
+        G = 1;
+      }
+    }
     h->G = G;
     if (G > 1) {
+      {
+        // the first group-mode handle on a device drains it once: launches enqueued before were not recorded (DeviceGate)
+        DeviceGate &g = device_gate(h->device);
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (g.group_handles++ == 0) (void)hipDeviceSynchronize();
+        h->gated = true;
+      }
       const unsigned int *nou = nullptr;
       if ((rc = upload(h, &h->d_gsync, nou, (size_t)h->grid * SPICEY_GRP_SYNC_WORDS)) != SPICEY_OK) return fail(rc);
       const int32_t *noi = nullptr;
@@ -355,6 +455,10 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   if (h->opt.profile)
     // (+ per-front event times behind the per-workgroup section timers)
     if ((rc = upload(h, &h->d_prof, noull, (size_t)h->grid * h->G * 72 + (size_t)h->grid * 4 * (size_t)P.nFronts)) != SPICEY_OK) return fail(rc);
+  if (h->opt.diagnostics & 1)
+    if ((rc = upload(h, &h->d_skip, noull, ni)) != SPICEY_OK) return fail(rc);
+  if ((h->opt.diagnostics & 2) && P.nD > 0)
+    if ((rc = upload(h, &h->d_linvd, nodbl, ni * P.nD)) != SPICEY_OK) return fail(rc);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     h->err = "stream/event creation failed";
     return fail(SPICEY_ERR_HIP);
@@ -395,6 +499,28 @@ extern "C" int32_t spicey_get_info(SpiceyHandle *h, SpiceyInfo *info) {
   return SPICEY_OK;
 }
 
+// enqueue the kernel of a prepared launch behind its device's admission gate; ev0 / ev1 bracket the kernel alone
+static int32_t enqueue_kernel(SpiceyHandle *h, const SpiceyRun &R, hipStream_t st) {
+  DeviceGate &g = device_gate(h->device);
+  std::lock_guard<std::mutex> lk(g.mu);  // (wait, launch and record are one step with respect to other launches)
+  const bool group = h->G > 1;
+  int slot = -1;
+  HIPCHK(h, gate_before_launch(g, group, st, &slot));
+  HIPCHK(h, hipEventRecord(h->ev0, st));  // (argument upload, flag resets and admission waits stay outside the timed kernel)
+  if (h->interp == 2) {
+    HIPCHK(h, spicey_launch_tran_v2(h->dprog, h->dres, h->d_Pstruct, h->d_Qstruct, h->d_Rstruct, h->K, h->grid, h->T, st, h->packed));
+  } else if (group) {
+    HIPCHK(h, spicey_launch_tran_grp(h->dprog, R, h->K, h->grid, h->T, st));
+  } else {
+    HIPCHK(h, spicey_launch_tran(h->dprog, R, h->K, h->lds, h->grid, h->T, st));
+  }
+  HIPCHK(h, hipEventRecord(h->ev1, st));
+  HIPCHK(h, gate_after_launch(g, group, st, slot));
+  return SPICEY_OK;
+}
+
+static size_t prof_words(const SpiceyHandle *h) { return (size_t)h->grid * h->G * 72 + (size_t)h->grid * 4 * (size_t)h->hp.hdr.nFronts; }
+
 extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, const double *d_src_table, double *d_out_v,
                                      double *d_out_i, int32_t *d_iters, void *stream) {
   if (!h) return SPICEY_ERR_BAD_DESC;
@@ -405,6 +531,12 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   }
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
+  // a run still in flight on ANOTHER stream: this launch would reset status words, barrier words and front flags under
+  // it — finish it first (its result is then reported here instead of by the next spicey_sync)
+  if (h->pending && h->last_stream != st) {
+    const int32_t rc0 = spicey_sync(h);
+    if (rc0 != SPICEY_OK) return rc0;
+  }
   SpiceyRun R{};
   R.n_inst = h->n_inst;
   R.want_currents = d_out_i != nullptr;
@@ -419,7 +551,26 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
   R.gstat = h->d_gstat; R.statv = h->d_statv; R.rcoef = h->d_rcoef; R.gW = h->d_gW; R.dpar = h->d_dpar;
   R.src = d_src_table; R.out_v = d_out_v; R.out_i = d_out_i; R.iters = d_iters;
   R.status = h->d_status; R.solves = h->d_solves; R.prof = h->d_prof;
-  if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, ((size_t)h->grid * h->G * 72 + (size_t)h->grid * 4 * (size_t)h->hp.hdr.nFronts) * sizeof(unsigned long long), st));
+  if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, prof_words(h) * sizeof(unsigned long long), st));
+  // diagnostics: counters and per-step maxima start from zero in every run
+  h->last_steps = steps;
+  if (h->d_skip) {
+    HIPCHK(h, hipMemsetAsync(h->d_skip, 0, (size_t)h->n_inst * sizeof(unsigned long long), st));
+    R.skip_risk = h->d_skip;
+  }
+  if (h->opt.diagnostics & 2) {
+    const size_t need = (size_t)h->n_inst * (size_t)(steps + 1);
+    if (need > h->linerr_cap) {
+      if (h->pending) { const int32_t rc0 = spicey_sync(h); if (rc0 != SPICEY_OK) return rc0; }
+      if (h->d_linerr) (void)hipFree(h->d_linerr);
+      h->d_linerr = nullptr; h->linerr_cap = 0;
+      HIPCHK(h, hipMalloc((void **)&h->d_linerr, need * sizeof(unsigned long long)));
+      h->linerr_cap = need;
+    }
+    HIPCHK(h, hipMemsetAsync(h->d_linerr, 0, need * sizeof(unsigned long long), st));
+    R.lin_err = h->d_linerr;
+    R.lin_vd = h->d_linvd;  // (null without diodes: the error stays 0)
+  }
   R.front_ticks = (h->d_prof && h->hp.hdr.nFronts > 0) ? h->d_prof + (size_t)h->grid * h->G * 72 : nullptr;
   R.wgs_per_group = h->G;
   R.grp_sync = h->d_gsync;
@@ -433,31 +584,31 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
     R.front_lds_doubles = (h->opt.debug & 8) ? 6144 : SPICEY_FRONT_LDS_DOUBLES;  // diagnostics: bit 3 = stage every front above 64 rows through panels
     HIPCHK(h, hipMemsetAsync(h->d_front_flags, 0, (size_t)h->grid * 2 * (size_t)h->hp.hdr.nFronts * sizeof(unsigned int), st));
   }
+  if (h->G > 1) {
+    HIPCHK(h, hipMemsetAsync(h->d_gsync, 0, (size_t)h->grid * SPICEY_GRP_SYNC_WORDS * sizeof(unsigned int), st));
+    // longest single cross-workgroup wait, in ticks of the chip-wide 100 MHz counter
+    int ms = h->opt.group_timeout_ms;
+    if (ms <= 0) { const char *e = getenv("SPICEY_GROUP_TIMEOUT_MS"); ms = e ? atoi(e) : 0; }
+    if (ms <= 0) ms = 5000;
+    R.grp_timeout_ticks = (unsigned long long)ms * 100000ull;
+    if (h->opt.group_retry) {
+      // the state entering this launch, for the one relaunch after a bounded-wait abort (spicey_sync)
+      const SpiceyProg &P = h->hp.hdr;
+      const size_t ni = (size_t)h->n_inst;
+      if (P.nC) HIPCHK(h, hipMemcpyAsync(h->d_Cv_s, h->d_Cv, ni * P.nC * sizeof(double), hipMemcpyDeviceToDevice, st));
+      if (P.nL) HIPCHK(h, hipMemcpyAsync(h->d_Li_s, h->d_Li, ni * P.nL * sizeof(double), hipMemcpyDeviceToDevice, st));
+      if (P.nD) HIPCHK(h, hipMemcpyAsync(h->d_Dv_s, h->d_Dv, ni * P.nD * sizeof(double), hipMemcpyDeviceToDevice, st));
+      if (P.nS) HIPCHK(h, hipMemcpyAsync(h->d_Son_s, h->d_Son, ni * P.nS * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    }
+    R.force_abort = getenv("SPICEY_TEST_FORCE_GROUP_ABORT") != nullptr ? 1 : 0;  // tests: the first attempt of every launch aborts
+    h->grp_R = R;
+  }
   if (h->interp == 2) {
     h->run_args = R;
     HIPCHK(h, hipMemcpyAsync(h->d_Rstruct, &h->run_args, sizeof(SpiceyRun), hipMemcpyHostToDevice, st));
   }
-  if (h->G > 1) {
-    HIPCHK(h, hipMemsetAsync(h->d_gsync, 0, (size_t)h->grid * SPICEY_GRP_SYNC_WORDS * sizeof(unsigned int), st));
-    // the state entering this launch, for the one relaunch after a bounded-spin abort (spicey_sync)
-    const SpiceyProg &P = h->hp.hdr;
-    const size_t ni = (size_t)h->n_inst;
-    if (P.nC) HIPCHK(h, hipMemcpyAsync(h->d_Cv_s, h->d_Cv, ni * P.nC * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (P.nL) HIPCHK(h, hipMemcpyAsync(h->d_Li_s, h->d_Li, ni * P.nL * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (P.nD) HIPCHK(h, hipMemcpyAsync(h->d_Dv_s, h->d_Dv, ni * P.nD * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (P.nS) HIPCHK(h, hipMemcpyAsync(h->d_Son_s, h->d_Son, ni * P.nS * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    R.force_abort = getenv("SPICEY_TEST_FORCE_GROUP_ABORT") != nullptr ? 1 : 0;  // tests: the first attempt of every launch aborts
-    h->grp_R = R;
-  }
-  HIPCHK(h, hipEventRecord(h->ev0, st));  // (argument upload and flag resets stay outside the timed kernel)
-  if (h->interp == 2) {
-    HIPCHK(h, spicey_launch_tran_v2(h->dprog, h->dres, h->d_Pstruct, h->d_Qstruct, h->d_Rstruct, h->K, h->grid, h->T, st, h->packed));
-  } else if (h->G > 1) {
-    HIPCHK(h, spicey_launch_tran_grp(h->dprog, R, h->K, h->grid, h->T, st));
-  } else {
-    HIPCHK(h, spicey_launch_tran(h->dprog, R, h->K, h->lds, h->grid, h->T, st));
-  }
-  HIPCHK(h, hipEventRecord(h->ev1, st));
+  const int32_t rc = enqueue_kernel(h, R, st);
+  if (rc != SPICEY_OK) return rc;
   h->pending = true;
   h->last_stream = st;
   return SPICEY_OK;
@@ -470,7 +621,7 @@ extern "C" int32_t spicey_sync(SpiceyHandle *h) {
   std::vector<int32_t> status((size_t)h->grid * 4);
   std::vector<unsigned long long> solves((size_t)h->grid);
   int best = -1;
-  bool repeated = false;
+  std::string aborted;  // text of an aborted attempt that was repeated
   for (int attempt = 0;; attempt++) {
     HIPCHK(h, hipStreamSynchronize(h->last_stream));
     h->pending = false;
@@ -480,26 +631,33 @@ extern "C" int32_t spicey_sync(SpiceyHandle *h) {
     HIPCHK(h, hipMemcpy(solves.data(), h->d_solves, solves.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     h->last_solves = 0;
     for (auto s : solves) h->last_solves += (int64_t)s;
+    std::vector<unsigned int> gsync;
+    if (h->G > 1 && h->d_gsync) {
+      gsync.resize((size_t)h->grid * SPICEY_GRP_SYNC_WORDS);
+      HIPCHK(h, hipMemcpy(gsync.data(), h->d_gsync, gsync.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+      for (int g = 0; g < h->grid; g++) h->stale_polls += (int64_t)gsync[(size_t)g * SPICEY_GRP_SYNC_WORDS + 8];
+    }
     // earliest failure wins (the reference throws at the first singular solve)
     best = -1;
     for (int g = 0; g < h->grid; g++)
       if (status[(size_t)g * 4] != 0 && (best < 0 || status[(size_t)g * 4 + 2] < status[(size_t)best * 4 + 2])) best = g;
     if (best < 0 || status[(size_t)best * 4] != 3) break;
     // (the first workgroup that gave up left a note in its group's barrier words, GpuGroupExec::note_timeout)
-    unsigned int note[8] = {0};
-    if (h->d_gsync) (void)hipMemcpy(note, h->d_gsync + (size_t)best * SPICEY_GRP_SYNC_WORDS, sizeof(note), hipMemcpyDeviceToHost);
-    char buf[256];
-    snprintf(buf, sizeof(buf), "cross-workgroup barrier timed out (group mode) at step %d: %s, workgroup %u (XCD %u), %s %u, waited for %u, saw %u",
-             status[(size_t)best * 4 + 2], note[2] == 2 ? "front hand-over" : note[2] == 3 ? "census barrier" : note[2] == 1 ? "group barrier" : "abort word raised",
-             note[3], note[7], note[2] == 2 ? "flag word" : "barrier", note[4], note[5], note[6]);
+    const unsigned int none[9] = {0};
+    const unsigned int *note = gsync.empty() ? none : gsync.data() + (size_t)best * SPICEY_GRP_SYNC_WORDS;
+    const char *kind = note[2] == 2 ? "front hand-over" : note[2] == 3 ? "census barrier" : note[2] == 1 ? "group barrier" : note[2] == 4 ? "XCD census does not add up" : "abort word raised";
+    char buf[384];
+    snprintf(buf, sizeof(buf), "cross-workgroup wait timed out (group mode) at step %d: %s, group %d of %d, workgroup %u of %d (XCD %u), %s %u, waited for %u, saw %u; %d threads, %d fronts, timeout %.0f ms",
+             status[(size_t)best * 4 + 2], kind, best, h->grid, note[3], h->G, note[7], note[2] == 2 ? "front flag" : "barrier", note[4], note[5], note[6], h->T,
+             h->hp.hdr.nFronts, (double)h->grp_R.grp_timeout_ticks / 1e5);
     h->err = buf;
-    if (attempt > 0 || h->G <= 1) return SPICEY_ERR_HIP;
-    // The bounded spin turned what would have been a hang into an abort; nothing of the aborted launch is kept.  The
-    // launch is repeated ONCE from the state it started with (the kernel writes state only in its last step, but that
+    fprintf(stderr, "spicey: %s%s\n", buf, (attempt == 0 && h->opt.group_retry) ? " -- repeating the launch once (SpiceyOptions.group_retry)" : "");
+    if (attempt > 0 || h->G <= 1 || !h->opt.group_retry) return SPICEY_ERR_HIP;
+    // The bounded wait turned what would have been a hang into an abort; nothing of the aborted launch is kept.  On request
+    // the launch is repeated ONCE from the state it started with (the kernel writes state only in its last step, but that
     // step may be the one that aborted): same arguments, same stream, fresh barrier words and front flags.
     h->group_retries++;
-    repeated = true;
-    fprintf(stderr, "spicey: %s -- repeating the launch once\n", buf);
+    aborted = buf;
     const SpiceyProg &P = h->hp.hdr;
     const size_t ni = (size_t)h->n_inst;
     hipStream_t st = h->last_stream;
@@ -509,14 +667,14 @@ extern "C" int32_t spicey_sync(SpiceyHandle *h) {
     if (P.nS) HIPCHK(h, hipMemcpyAsync(h->d_Son, h->d_Son_s, ni * P.nS * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipMemsetAsync(h->d_gsync, 0, (size_t)h->grid * SPICEY_GRP_SYNC_WORDS * sizeof(unsigned int), st));
     if (P.nFronts > 0) HIPCHK(h, hipMemsetAsync(h->d_front_flags, 0, (size_t)h->grid * 2 * (size_t)P.nFronts * sizeof(unsigned int), st));
-    if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, ((size_t)h->grid * h->G * 72 + (size_t)h->grid * 4 * (size_t)P.nFronts) * sizeof(unsigned long long), st));
+    if (h->d_prof) HIPCHK(h, hipMemsetAsync(h->d_prof, 0, prof_words(h) * sizeof(unsigned long long), st));
     h->grp_R.force_abort = 0;
-    HIPCHK(h, hipEventRecord(h->ev0, st));
-    HIPCHK(h, spicey_launch_tran_grp(h->dprog, h->grp_R, h->K, h->grid, h->T, st));
-    HIPCHK(h, hipEventRecord(h->ev1, st));
+    const int32_t rc = enqueue_kernel(h, h->grp_R, st);
+    if (rc != SPICEY_OK) return rc;
     h->pending = true;
   }
-  if (repeated && best < 0) h->err.clear();
+  // (the text of an aborted attempt stays readable although its repetition went through)
+  if (!aborted.empty() && best < 0) h->err = "recovered: " + aborted;
   if (best >= 0) {
     char buf[160];
     snprintf(buf, sizeof(buf), "singular at inst %d step %d iter %d", status[(size_t)best * 4 + 1], status[(size_t)best * 4 + 2],
@@ -528,6 +686,7 @@ extern "C" int32_t spicey_sync(SpiceyHandle *h) {
 }
 
 extern "C" int32_t spicey_group_retries(const SpiceyHandle *h) { return h ? h->group_retries : 0; }
+extern "C" int64_t spicey_group_stale_polls(const SpiceyHandle *h) { return h ? h->stale_polls : 0; }
 
 extern "C" int32_t spicey_run(SpiceyHandle *h, int64_t steps, double dt, const double *src_table, double *out_v, double *out_i,
                               int32_t *iters) {
@@ -622,6 +781,27 @@ extern "C" int32_t spicey_reset_state(SpiceyHandle *h, void *stream) {
 }
 
 extern "C" int64_t spicey_last_solve_count(SpiceyHandle *h) { return h ? h->last_solves : 0; }
+
+extern "C" int64_t spicey_last_skip_risk(SpiceyHandle *h, int64_t *per_inst) {
+  if (!h || !h->d_skip) return -1;
+  if (spicey_sync(h) == SPICEY_ERR_HIP) return -1;
+  std::vector<unsigned long long> tmp((size_t)h->n_inst);
+  if (hipSetDevice(h->device) != hipSuccess || hipMemcpy(tmp.data(), h->d_skip, tmp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  int64_t tot = 0;
+  for (size_t i = 0; i < tmp.size(); i++) { tot += (int64_t)tmp[i]; if (per_inst) per_inst[i] = (int64_t)tmp[i]; }
+  return tot;
+}
+
+extern "C" int32_t spicey_get_lin_err(SpiceyHandle *h, double *out) {
+  if (!h || !out) return SPICEY_ERR_BAD_DESC;
+  if (!(h->opt.diagnostics & 2) || !h->d_linerr || h->last_steps < 0) { h->err = "spicey_get_lin_err needs SpiceyOptions.diagnostics bit 1 and a finished run"; return SPICEY_ERR_BAD_DESC; }
+  const int32_t rc = spicey_sync(h);
+  if (rc != SPICEY_OK && rc != SPICEY_ERR_SINGULAR) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  // (bit patterns of non-negative doubles: a plain copy)
+  HIPCHK(h, hipMemcpy(out, h->d_linerr, (size_t)h->n_inst * (size_t)(h->last_steps + 1) * sizeof(double), hipMemcpyDeviceToHost));
+  return SPICEY_OK;
+}
 extern "C" double spicey_last_kernel_ms(SpiceyHandle *h) { return h ? h->last_ms : 0.0; }
 
 extern "C" int32_t spicey_debug_phase_cycles(SpiceyHandle *h, uint64_t *out, int32_t n) {
@@ -789,5 +969,15 @@ extern "C" int32_t spicey_multi_get_shard(SpiceyMulti *m, int32_t shard, SpiceyI
   return SPICEY_OK;
 }
 
+extern "C" int32_t spicey_multi_group_retries(SpiceyMulti *m) {
+  int32_t n = 0;
+  if (m) for (auto &s : m->shards) n += spicey_group_retries(s.h);
+  return n;
+}
+extern "C" int64_t spicey_multi_group_stale_polls(SpiceyMulti *m) {
+  int64_t n = 0;
+  if (m) for (auto &s : m->shards) n += spicey_group_stale_polls(s.h);
+  return n;
+}
 extern "C" int64_t spicey_multi_last_solve_count(SpiceyMulti *m) { return m ? m->last_solves : 0; }
 extern "C" double spicey_multi_last_kernel_ms(SpiceyMulti *m) { return m ? m->last_ms : 0.0; }

@@ -1362,6 +1362,18 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
   for (int c = 0; c < n; c++) hp.pos_col[hp.cpos[c]] = c;
   hp.ent_ro.assign(nLU, 0); hp.ent_co.assign(nLU, 0);
   for (int e = 0; e < nLU; e++) { hp.ent_ro[e] = hp.pos_row[E.row_of_id[e]]; hp.ent_co[e] = hp.pos_col[E.col_of_id[e]]; }
+  // structural entries of A by natural column (diagnostics: program.h, col_ptr / col_ent)
+  {
+    std::vector<std::vector<uint32_t>> by_col(n);
+    for (int e = 0; e < nLU; e++)
+      if (!stat[e].empty() || !dyn[e].empty()) by_col[hp.ent_co[e]].push_back((uint32_t)e | ((hp.ent_flag[e] & 1) ? SPICEY_TGT_RECIP : 0u));
+    hp.col_ptr.assign(1, 0u);
+    hp.col_ent.clear();
+    for (int c = 0; c < n; c++) {
+      hp.col_ent.insert(hp.col_ent.end(), by_col[c].begin(), by_col[c].end());
+      hp.col_ptr.push_back((uint32_t)hp.col_ent.size());
+    }
+  }
 
   hp.pack();
   return SPICEY_OK;
@@ -1422,6 +1434,7 @@ void HostProgram::pack() {
   add_section(blob, offsets, ent_ro); add_section(blob, offsets, ent_co);        // 59 60
   add_section(blob, offsets, pos_row); add_section(blob, offsets, pos_col);      // 61 62
   add_section(blob, offsets, bin_upd); add_section(blob, offsets, bin_bk);       // 63 64
+  add_section(blob, offsets, col_ptr); add_section(blob, offsets, col_ent);      // 65 66
 }
 
 SpiceyProg HostProgram::bind(const void *base) const {
@@ -1448,6 +1461,7 @@ SpiceyProg HostProgram::bind(const void *base) const {
   p.fus16 = u32(54); p.fus_first = u32(55); p.fus_gen = u32(56); p.fus_rhs = u32(57); p.fus_pairs = u32(58);
   p.ent_ro = i32(59); p.ent_co = i32(60); p.pos_row = i32(61); p.pos_col = i32(62);
   p.bin_upd = u32(63); p.bin_bk = u32(64);
+  p.col_ptr = u32(65); p.col_ent = u32(66);
   return p;
 }
 

@@ -39,6 +39,7 @@ struct HostProgram {
   std::vector<SpiceyFront> fronts;
   std::vector<uint32_t> fr_asm, fr_bnd, fr_child, fr_rel;
   std::vector<uint32_t> bin_upd, bin_bk;  // subtree-local levels below the cut (program.h)
+  std::vector<uint32_t> col_ptr, col_ent;  // structural entries of A by natural column (diagnostics, program.h)
   std::vector<double> front_work;  // multiply-adds of each front's partial factorisation (for the schedule)
 
   // Serialise all arrays into one blob (16-byte aligned sections) and return a SpiceyProg whose

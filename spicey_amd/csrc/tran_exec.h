@@ -56,6 +56,19 @@
 #else
 #define SPICEY_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #endif
+// diagnostics (SpiceyRun::skip_risk / lin_err): 64-bit integer atomics on global memory; the maximum over a wave by
+// cross-lane shuffles (every lane of the wave must arrive: call it outside divergent branches); one lane per wave reports
+#define SPICEY_ATOMIC_ADD_U64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
+#define SPICEY_ATOMIC_MAX_U64(p, v) atomicMax((unsigned long long *)(p), (unsigned long long)(v))
+static __device__ __forceinline__ double spicey_wave_max(double x) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const double y = __shfl_xor(x, off);
+    x = (y > x) ? y : x;
+  }
+  return x;
+}
+#define SPICEY_WAVE_MAX(x) spicey_wave_max(x)
+#define SPICEY_WAVE_LEADER(tid) (((tid) & 63) == 0)
 #define SPICEY_NOUNROLL _Pragma("unroll 1")  // thread-strided loops run 1-2 trips: unrolling only costs VGPRs
 #define SPICEY_UNROLL _Pragma("unroll")      // small fixed-trip loops over a register array: without it the array is indexed through s_set_gpr_idx
 #define SPICEY_SCHED_FENCE __builtin_amdgcn_sched_barrier(0)  // keep the K instances' code from being interleaved
@@ -68,6 +81,10 @@
 #define SPICEY_OPAQUE_S(x) (void)(x)
 #define SPICEY_WAVE_ANY(c) true
 #define SPICEY_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#define SPICEY_ATOMIC_ADD_U64(p, v) (*(p) += (unsigned long long)(v))
+#define SPICEY_ATOMIC_MAX_U64(p, v) do { if ((unsigned long long)(v) > *(p)) *(p) = (unsigned long long)(v); } while (0)
+#define SPICEY_WAVE_MAX(x) (x)  // (the emulator runs one thread at a time: every thread reports for itself)
+#define SPICEY_WAVE_LEADER(tid) true
 #endif
 
 // phase tags (profiling slots, SpiceyRun::prof)
@@ -139,12 +156,53 @@ SPICEY_HD double spicey_switch_g(int on, double ron, double roff) {  // simulate
   return 1.0 / spicey_max_nan(fabs(r), SPICEY_EPS);
 }
 
+// ---- diagnostics -------------------------------------------------------------------------------------------------------
+// Right after phase B the workspace holds the stamped matrix A (leaf diagonals as reciprocals).  The reference eliminates
+// with partial pivoting, so its multiplier for row i at column k is a_ik / max_j |a_jk| (of the matrix as updated so far)
+// and `if (Math.abs(f) < EPS) continue` (solveReal.ts:45) SKIPS the row update when that is below 1e-15 — a nonzero
+// coupling silently dropped, which a static sparse order does not reproduce (deviations).  This pass counts the
+// columns of the STAMPED matrix in which some nonzero entry is below 1e-15 x the column's largest: the first-order
+// indicator of that situation (exact for the first pivot; fills and updated entries are not looked at).  One thread per
+// column, read-only, no influence on the solve.  `weight` = solves the count stands for (a linear circuit's matrix is
+// looked at once, at step 0, for all its steps).
+template <int K>
+SPICEY_HD void spicey_skip_risk(const SpiceyProg &P, const SpiceyRun &R, const WgCtx<K> &c, int tid, int T, unsigned long long weight) {
+  SPICEY_NOUNROLL
+  for (int col = tid; col < P.n; col += T) {
+    const uint32_t j0 = P.col_ptr[col], j1 = P.col_ptr[col + 1];
+    for (int k = 0; k < K; k++) {
+      if (!c.valid[k]) continue;
+      double mx = 0.0, mn = 1.0e308;
+      bool any = false;
+      for (uint32_t j = j0; j < j1; j++) {
+        const uint32_t e = P.col_ent[j];
+        double v = fabs(c.W[(size_t)SPICEY_IDX(e) * K + k]);
+        if (e & SPICEY_TGT_RECIP) v = 1.0 / v;
+        if (v != 0.0) { any = true; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+      }
+      if (any && mn / mx < SPICEY_EPS) SPICEY_ATOMIC_ADD_U64(R.skip_risk + c.inst[k], weight);  // (a quotient, like the reference's f)
+    }
+  }
+}
+// the one-shot linearisation error of a step (SpiceyRun::lin_err): every wave reports the largest |vd(x) - vd_lin| of its diodes
+SPICEY_HD void spicey_lin_err_report(const SpiceyRun &R, size_t inst, int64_t step, int tid, double lerr) {
+  const double m = SPICEY_WAVE_MAX(lerr);
+  if (SPICEY_WAVE_LEADER(tid) && m > 0.0) {
+    unsigned long long bits;
+    __builtin_memcpy(&bits, &m, 8);
+    SPICEY_ATOMIC_MAX_U64(R.lin_err + inst * (size_t)(R.steps + 1) + (size_t)step, bits);
+  }
+}
+
 template <int K>
 struct TranPhases {
   const SpiceyProg &P;
   const SpiceyRun &R;
   WgCtx<K> &c;
   int T;  // threads
+  // the diagnostics of SpiceyOptions.diagnostics are compiled into the kernels with K <= 2 only (the 4-instance kernels have
+  // no registers to spare: with them the build reports a stack frame); the host keeps K <= 2 when the option is set
+  static constexpr bool DIAG = K <= 2;
 
   SPICEY_HD double volt(int32_t xi, int k) const { return xi < 0 ? 0.0 : c.W[(size_t)xi * K + k]; }
 
@@ -220,6 +278,7 @@ struct TranPhases {
         spicey_diode(R.D_vdprev[in * P.nD + i], R.D_is[in * P.nD + i], R.D_n[in * P.nD + i], g, q);
         c.gd[(size_t)(P.nS + i) * K + k] = g;
         c.u[(size_t)(oD + i) * K + k] = q;
+        if (DIAG && R.lin_vd && c.valid[k]) R.lin_vd[in * P.nD + i] = R.D_vdprev[in * P.nD + i];
       }
     }
     static_copy(tid, true);
@@ -429,9 +488,11 @@ struct TranPhases {
       SPICEY_NOUNROLL
       for (int i = tid; i < P.nD; i += T) {
         double g, q;
-        spicey_diode(volt(P.D_a[i], k) - volt(P.D_b[i], k), R.D_is[in * P.nD + i], R.D_n[in * P.nD + i], g, q);
+        const double vd = volt(P.D_a[i], k) - volt(P.D_b[i], k);
+        spicey_diode(vd, R.D_is[in * P.nD + i], R.D_n[in * P.nD + i], g, q);
         c.gd[(size_t)(P.nS + i) * K + k] = g;
         c.u[(size_t)(oD + i) * K + k] = q;
+        if (DIAG && R.lin_vd && c.valid[k]) R.lin_vd[in * P.nD + i] = vd;
       }
     }
     static_copy(tid);
@@ -482,6 +543,7 @@ struct TranPhases {
         c.gd[(size_t)i * K + k] = gs;
         if (last) R.S_ison[in * P.nS + i] = on;
       }
+      double lerr = 0.0;
       SPICEY_NOUNROLL
       for (int i = tid; i < P.nD; i += T) {
         const double vd = volt(P.D_a[i], k) - volt(P.D_b[i], k);
@@ -493,7 +555,13 @@ struct TranPhases {
         c.gd[(size_t)(P.nS + i) * K + k] = gg;
         c.u[(size_t)(oD + i) * K + k] = q;
         if (last) R.D_vdprev[in * P.nD + i] = vd;
+        if (DIAG && R.lin_vd) {  // diagnostics: how far the junction moved from where this solve had it linearised
+          const double e = fabs(vd - R.lin_vd[in * P.nD + i]);
+          lerr = e > lerr ? e : lerr;
+          R.lin_vd[in * P.nD + i] = vd;
+        }
       }
+      if (DIAG && R.lin_err) spicey_lin_err_report(R, in, step, tid, lerr);
     }
     if (!keep_factors) static_copy(tid);  // a linear circuit keeps the factors of step 0 in W
   }
@@ -755,6 +823,10 @@ struct TranPhases2 {
   // arithmetic and a branch: ~1200 cycles per step in Z alone before they were put behind one test.
   uint32_t brem, zrem;
   typedef ResRegs<K, RMAX, NSV, NEL> Regs;
+  // the diagnostics of SpiceyOptions.diagnostics are compiled into every geometry but the two-workgroups-per-CU one (NSV = 6:
+  // 128 VGPRs and nothing to spare — with them that kernel spills, which the build refuses); the host keeps a handle with
+  // the option out of that geometry
+  static constexpr bool DIAG = NSV != 6;
   SPICEY_HD void set_remainders() {
     brem = (P.nRestore > NSV * T ? 1u : 0u) | (P.nDynX > 0 ? 2u : 0u) | (P.n > NEL * T ? 4u : 0u) | (P.nRowX > 0 ? 8u : 0u) |
            (P.nDynEnt > Regs::NDD * T ? 16u : 0u);
@@ -835,6 +907,7 @@ struct TranPhases2 {
         spicey_diode_k(R.D_vdprev[in * P.nD + i], R.D_is[in * P.nD + i], dp[0], dp[1], false, g2, q, irec);
         c.gd[(size_t)(P.nS + i) * K + k] = g2;
         c.u[(size_t)(oD + i) * K + k] = q;
+        if (DIAG && R.lin_vd && c.valid[k]) R.lin_vd[in * P.nD + i] = R.D_vdprev[in * P.nD + i];
       }
     }
     if (tid == 0) c.flags[0] = 0;
@@ -975,9 +1048,11 @@ struct TranPhases2 {
       for (int i = tid; i < P.nD; i += T) {
         const double *dp = R.dpar + (in * P.nD + i) * 2;
         double g2, q, irec;
-        spicey_diode_k(dv16(P.D_ab[i], k), R.D_is[in * P.nD + i], dp[0], dp[1], false, g2, q, irec);
+        const double vd = dv16(P.D_ab[i], k);
+        spicey_diode_k(vd, R.D_is[in * P.nD + i], dp[0], dp[1], false, g2, q, irec);
         c.gd[(size_t)(P.nS + i) * K + k] = g2;
         c.u[(size_t)(oD + i) * K + k] = q;
+        if (DIAG && R.lin_vd && c.valid[k]) R.lin_vd[in * P.nD + i] = vd;
       }
     }
   }
@@ -996,6 +1071,19 @@ struct TranPhases2 {
     c.gd[(size_t)(P.nS + i) * K + k] = gg;
     c.u[(size_t)(oD + i) * K + k] = q;
     if (last) R.D_vdprev[in * P.nD + i] = vd;
+  }
+  // diagnostics pass of Z (SpiceyRun::lin_vd set; its own loop so that the production path carries no extra state):
+  // |vd(x) - vd_lin| of this thread's diodes, and the new linearisation point
+  SPICEY_HD double z_lin_err(int tid, int k, size_t in) const {
+    double lerr = 0.0;
+    SPICEY_NOUNROLL
+    for (int i = tid; i < P.nD; i += T) {
+      const double vd = dv16(P.D_ab[i], k);
+      const double e = fabs(vd - R.lin_vd[in * P.nD + i]);
+      lerr = e > lerr ? e : lerr;
+      R.lin_vd[in * P.nD + i] = vd;
+    }
+    return lerr;
   }
   SPICEY_HD void z_prefetch(int tid, int64_t step, int k, Regs &rr) const {
     const size_t in = (size_t)(K == 1 ? c.inst[0] : (k == 0 ? c.inst[0] : c.inst[K - 1]));
@@ -1036,6 +1124,10 @@ struct TranPhases2 {
       double *ov = R.out_v + (in * (size_t)(R.steps + 1) + (size_t)step) * P.nOut;
       double *oi = R.out_i ? R.out_i + (in * (size_t)(R.steps + 1) + (size_t)step) * P.nCur : nullptr;
       const double *g = R.gstat + in * P.nGstat;
+      if (DIAG && R.lin_vd) {  // diagnostics (wave-uniform): the step's one-shot linearisation error
+        const double lerr = z_lin_err(tid, k, in);
+        if (R.lin_err) spicey_lin_err_report(R, in, step, tid, lerr);
+      }
       SPICEY_MARK(c, 15);
       // Element parameters of the resident items come from L2: all their loads are issued together (one round
       // trip per step instead of one per element section), normally already during the last backward phase.
@@ -1280,6 +1372,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
   // factors stay in W and later steps run the right-hand-side column only.  Same operands, same order: the results
   // are bit-identical to refactoring (SURVEY.md §8(d) "solve-only" rate; the reference itself never reuses).
   top_pack |= (P.nD == 0 && nS == 0 && P.nDynEnt == 0 && !R.no_reuse) ? 1 << 17 : 0;  // bit 17 = linear
+  top_pack |= (Ph2::DIAG && R.skip_risk != nullptr) ? 1 << 18 : 0;  // bit 18 = diagnostics: look at the stamped matrix after B (spicey_skip_risk)
   top_pack = SPICEY_UNIFORM(top_pack);
   for (int64_t step = 0; step <= steps && code == 0; step++) {
     int iter = 0;
@@ -1287,7 +1380,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
       int tp = top_pack;
       SPICEY_OPAQUE_S(tp);
       const int pcr_n = tp & 0xff, pcr_S = (tp >> 8) & 0xff;
-      const bool z_pre = (tp >> 16) & 1, linear = (tp >> 17) & 1;
+      const bool linear = (tp >> 17) & 1;
       ex.phase(SPICEY_PH_B, [&](int tid) {
         const SpiceyProg Pf = ex.fresh(P);
         const SpiceyRun Rf = ex.fresh(R);
@@ -1300,6 +1393,12 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
         SPICEY_SCHED_FENCE;
         if (K == 1) p2.z_src_park(tid, sn);
       });
+      if (Ph2::DIAG && ((tp >> 18) & 1) && !(linear && step > 0))
+        ex.phase(SPICEY_PH_S, [&](int tid) {
+          const SpiceyProg Pf = ex.fresh(P);
+          const SpiceyRun Rf = ex.fresh(R);
+          spicey_skip_risk<K>(Pf, Rf, c, tid, T, linear ? (unsigned long long)(steps + 1) : 1ull);
+        });
       for (int d = 0; d < dbg_empty; d++) ex.phase(SPICEY_PH_S, [&](int) {});  // diagnostics: cost of a bare phase
       // factor levels [0, u_end) | tail [u_end, k_begin) by one wave | backward levels [k_begin, 2 nL)
       for (int p = 0; p < u_end; p++) {
@@ -1419,6 +1518,8 @@ SPICEY_HD void spicey_tran_run(Exec &ex, const SpiceyProg &P, const SpiceyRun &R
     int iter = 0;
     for (;;) {
       ex.phase(SPICEY_PH_B, [&](int tid) { ph.b_stamp(tid); });
+      if (TranPhases<K>::DIAG && R.skip_risk && !(linear && step > 0))  // diagnostics: the stamped matrix, before the factor levels touch it
+        ex.phase(SPICEY_PH_S, [&](int tid) { spicey_skip_risk<K>(P, R, c, tid, ex.threads(), linear ? (unsigned long long)(R.steps + 1) : 1ull); });
       ex.mark(SPICEY_PH_B);
       {
         // Group mode: runs of narrow factor levels (<= 1024 tasks, one per thread: the last pivots of the top separator) also go to

@@ -19,10 +19,10 @@ LIB_PATH = os.environ.get("SPICEY_HIP_LIB") or os.path.join(_HERE, "libspicey_hi
 _LIB = None
 
 EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "spicey_get_state", "spicey_set_state", "spicey_reset_state",
-           "spicey_last_solve_count", "spicey_group_retries",
+           "spicey_last_solve_count", "spicey_group_retries", "spicey_group_stale_polls", "spicey_last_skip_risk", "spicey_get_lin_err",
            "spicey_last_kernel_ms", "spicey_get_info", "spicey_last_error", "spicey_destroy", "spicey_version",
            "spicey_debug_phase_cycles", "spicey_debug_phase_cycles_wg", "spicey_debug_front_ticks",
-           "spicey_create_multi", "spicey_run_multi", "spicey_get_state_multi", "spicey_multi_get_shard", "spicey_multi_last_solve_count",
+           "spicey_create_multi", "spicey_run_multi", "spicey_get_state_multi", "spicey_multi_get_shard", "spicey_multi_last_solve_count", "spicey_multi_group_retries", "spicey_multi_group_stale_polls",
            "spicey_multi_last_kernel_ms", "spicey_multi_last_error", "spicey_destroy_multi",
            "spicey_ac_create", "spicey_ac_run", "spicey_ac_get_info", "spicey_ac_last_kernel_ms", "spicey_ac_last_error", "spicey_ac_destroy",
            "spicey_format_tran", "spicey_to_precision6"]
@@ -30,6 +30,12 @@ EXPORTS = ["spicey_create", "spicey_run", "spicey_run_device", "spicey_sync", "s
 
 class SpiceyNativeError(RuntimeError):
     pass
+
+
+# Group mode health of this process: launches repeated after a bounded-wait abort and waits that only the read-modify-write
+# poll saw satisfied, summed over every handle closed so far (include/spicey_hip.h: spicey_group_retries,
+# spicey_group_stale_polls).  Both stay 0 in a healthy process; the GPU tests assert that around every test.
+GROUP_TOTALS = {"retries": 0, "stale_polls": 0}
 
 
 def load():
@@ -51,6 +57,12 @@ def load():
     L.spicey_sync.argtypes = [vp]
     L.spicey_group_retries.restype = C.c_int32
     L.spicey_group_retries.argtypes = [vp]
+    L.spicey_group_stale_polls.restype = C.c_int64
+    L.spicey_group_stale_polls.argtypes = [vp]
+    L.spicey_last_skip_risk.restype = C.c_int64
+    L.spicey_last_skip_risk.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.spicey_get_lin_err.restype = C.c_int32
+    L.spicey_get_lin_err.argtypes = [vp, f64p]
     L.spicey_get_state.restype = C.c_int32
     L.spicey_get_state.argtypes = [vp, f64p, f64p, f64p, i32p]
     L.spicey_set_state.restype = C.c_int32
@@ -82,6 +94,10 @@ def load():
     L.spicey_multi_get_shard.argtypes = [vp, C.c_int32, C.POINTER(abi.SpiceyInfo), i32p, i32p, i32p]
     L.spicey_multi_last_solve_count.restype = C.c_int64
     L.spicey_multi_last_solve_count.argtypes = [vp]
+    L.spicey_multi_group_retries.restype = C.c_int32
+    L.spicey_multi_group_retries.argtypes = [vp]
+    L.spicey_multi_group_stale_polls.restype = C.c_int64
+    L.spicey_multi_group_stale_polls.argtypes = [vp]
     L.spicey_multi_last_kernel_ms.restype = C.c_double
     L.spicey_multi_last_kernel_ms.argtypes = [vp]
     L.spicey_multi_last_error.restype = C.c_char_p
@@ -117,7 +133,8 @@ class Handle:
 
     def __init__(self, flat: abi.FlatCircuit, device: int = 0, threads: int = 0, inst_per_wg: int = 0,
                  force_global: bool = False, profile: bool = False, interpreter: int = 0, geometry: int = 0, no_tail: bool = False, debug_empty_phases: int = 0, wgs_per_inst: int = 0,
-                 no_reuse: bool = False, csr_numbering: bool = False, front_cut: int = 0, stage_fronts: bool = False, no_pcr: bool = False, no_rows: bool = False):
+                 no_reuse: bool = False, csr_numbering: bool = False, front_cut: int = 0, stage_fronts: bool = False, no_pcr: bool = False, no_rows: bool = False,
+                 group_retry: bool = False, group_timeout_ms: int = 0, diagnostics: int = 0):
         self.L = load()
         self.flat = flat
         opt = abi.SpiceyOptions()
@@ -127,6 +144,8 @@ class Handle:
         opt.geometry = int(geometry)
         opt.wgs_per_inst = int(wgs_per_inst)
         opt.front_cut = int(front_cut)
+        opt.group_retry, opt.group_timeout_ms, opt.diagnostics = int(group_retry), int(group_timeout_ms), int(diagnostics)
+        self.diagnostics = int(diagnostics)
         opt.debug = (1 if no_tail else 0) | (2 if no_reuse else 0) | (4 if csr_numbering else 0) | (8 if stage_fronts else 0) | (32 if no_pcr else 0) | (64 if no_rows else 0) | (int(debug_empty_phases) << 8)
         d = flat.desc()
         hp = C.c_void_p()
@@ -160,6 +179,15 @@ class Handle:
             res["state"] = self.state()
             res["solves"] = self.L.spicey_last_solve_count(self.h)
             res["kernel_ms"] = self.L.spicey_last_kernel_ms(self.h)
+            if self.diagnostics & 1:
+                per = np.zeros(f.n_inst, np.int64)
+                self.L.spicey_last_skip_risk(self.h, _p(per, C.c_int64))
+                res["skip_risk"] = per
+            if self.diagnostics & 2:
+                le = np.zeros((f.n_inst, steps + 1))
+                if self.L.spicey_get_lin_err(self.h, _p(le, C.c_double)) != abi.OK:
+                    raise SpiceyNativeError(f"spicey_get_lin_err failed: {self.error()}")
+                res["lin_err"] = le
         return res
 
     def run_device(self, steps: int, dt: float, d_src: int, d_out_v: int, d_out_i: int = 0, d_iters: int = 0, stream: int = 0) -> None:
@@ -188,6 +216,10 @@ class Handle:
     def group_retries(self) -> int:
         """Group-mode launches this handle repeated after a bounded-spin abort (include/spicey_hip.h, spicey_sync)."""
         return self.L.spicey_group_retries(self.h)
+
+    def group_stale_polls(self) -> int:
+        """Group mode: waits of this handle's launches that only the read-modify-write poll saw satisfied (0 when healthy)."""
+        return self.L.spicey_group_stale_polls(self.h)
 
     def kernel_ms(self) -> float:
         return self.L.spicey_last_kernel_ms(self.h)
@@ -233,6 +265,8 @@ class Handle:
 
     def close(self) -> None:
         if getattr(self, "h", None):
+            GROUP_TOTALS["retries"] += self.L.spicey_group_retries(self.h)
+            GROUP_TOTALS["stale_polls"] += self.L.spicey_group_stale_polls(self.h)
             self.L.spicey_destroy(self.h)
             self.h = None
 
@@ -293,8 +327,16 @@ class MultiHandle:
             res["kernel_ms"] = self.L.spicey_multi_last_kernel_ms(self.h)
         return res
 
+    def group_retries(self) -> int:
+        return self.L.spicey_multi_group_retries(self.h)
+
+    def group_stale_polls(self) -> int:
+        return self.L.spicey_multi_group_stale_polls(self.h)
+
     def close(self) -> None:
         if getattr(self, "h", None):
+            GROUP_TOTALS["retries"] += self.L.spicey_multi_group_retries(self.h)
+            GROUP_TOTALS["stale_polls"] += self.L.spicey_multi_group_stale_polls(self.h)
             self.L.spicey_destroy_multi(self.h)
             self.h = None
 
@@ -381,17 +423,25 @@ class HipBackend:
     """Backend interface used by spicey_amd.simulate: one handle per call (the reference API is stateless)."""
 
     def __init__(self, device: int = 0, threads: int = 0, inst_per_wg: int = 0, force_global: bool = False, interpreter: int = 0,
-                 geometry: int = 0, wgs_per_inst: int = 0, no_reuse: bool = False, front_cut: int = 0, stage_fronts: bool = False, no_pcr: bool = False, no_rows: bool = False):
+                 geometry: int = 0, wgs_per_inst: int = 0, no_reuse: bool = False, front_cut: int = 0, stage_fronts: bool = False, no_pcr: bool = False, no_rows: bool = False,
+                 group_retry: bool = False, group_timeout_ms: int = 0, diagnostics: int = 0):
         self.kw = dict(device=device, threads=threads, inst_per_wg=inst_per_wg, force_global=force_global, interpreter=interpreter,
-                       geometry=geometry, wgs_per_inst=wgs_per_inst, no_reuse=no_reuse, front_cut=front_cut, stage_fronts=stage_fronts, no_pcr=no_pcr, no_rows=no_rows)
+                       geometry=geometry, wgs_per_inst=wgs_per_inst, no_reuse=no_reuse, front_cut=front_cut, stage_fronts=stage_fronts, no_pcr=no_pcr, no_rows=no_rows,
+                       group_retry=group_retry, group_timeout_ms=group_timeout_ms, diagnostics=diagnostics)
         self.info: Optional[dict] = None
+        self.group_retries = 0      # summed over this backend's runs (group mode; 0 when healthy)
+        self.group_stale_polls = 0
 
     def run(self, flat: abi.FlatCircuit, steps: int, dt: float, src: np.ndarray, want_currents: bool = True,
             want_iters: bool = True) -> dict:
         h = Handle(flat, **self.kw)
         try:
             self.info = h.info()
-            return h.run(steps, dt, src, want_currents, want_iters)
+            res = h.run(steps, dt, src, want_currents, want_iters)
+            self.group_retries += h.group_retries()
+            self.group_stale_polls += h.group_stale_polls()
+            res["group_retries"], res["group_stale_polls"] = h.group_retries(), h.group_stale_polls()
+            return res
         finally:
             h.close()
 

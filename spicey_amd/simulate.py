@@ -30,7 +30,8 @@ class SingularMatrixError(RuntimeError):
 def _default_backend():
     from .lib import HipBackend  # fails loudly if the extension is missing
 
-    return HipBackend()
+    # (diagnostics bit 0: the result says when the reference's row-update skip may have made ITS answer differ, `skipRisk`)
+    return HipBackend(diagnostics=1)
 
 
 def simulateTRAN(ckt: ParsedCircuit, backend=None, as_lists: bool = True) -> Optional[dict]:
@@ -59,7 +60,13 @@ def simulateTRAN(ckt: ParsedCircuit, backend=None, as_lists: bool = True) -> Opt
     names = ckt.nodes.rev
     node_voltages: Dict[str, object] = {}
     # JS: later duplicate names cannot occur (interned), order = js key order of insertion order
-    recorded = [int(i) for i in flat.out_nodes] if flat.out_nodes is not None and len(flat.out_nodes) else list(range(1, ckt.nodes.count()))
+    # (probes present but none of them names a node — the reference's parser does not intern `.PRINT TRAN v(x)` names,
+    # parseNetlist.ts:196-206 — : the reference's filter leaves nodeVoltages = {} (:240-249).  An empty out_nodes means "all
+    # nodes" to the device, so that case is told apart here: the device records what it must, nothing of it is keyed)
+    if len(ckt.probes["tran"]) > 0:
+        recorded = [int(i) for i in flat.out_nodes] if flat.out_nodes is not None else []
+    else:
+        recorded = list(range(1, ckt.nodes.count()))
     order = js_object_key_order([names[i] for i in recorded])
     col = {names[i]: c for c, i in enumerate(recorded)}
     for name in order:
@@ -93,8 +100,13 @@ def simulateTRAN(ckt: ParsedCircuit, backend=None, as_lists: bool = True) -> Opt
         s.isOn = bool(st["S_ison"][0, i])
 
     # (probes, if any, were applied on the device: node_voltages holds exactly the probed nodes, in JS key order)
+    # Beyond the reference's three keys: `iterations` (solves per step) and `skipRisk` — the number of (solve, column) pairs
+    # in which the stamped matrix had a nonzero entry below 1e-15 x its column's largest, i.e. where the reference's
+    # `if (Math.abs(f) < EPS) continue` (solveReal.ts:45) drops a row update that this solver performs (0: the two agree to
+    # the 1e-9 bar; > 0: the reference's own numbers may differ, include/spicey_hip.h spicey_last_skip_risk)
+    skip = res.get("skip_risk")
     return {"times": times, "nodeVoltages": node_voltages, "elementCurrents": element_currents,
-            "iterations": res.get("iters")}
+            "iterations": res.get("iters"), "skipRisk": int(skip[0]) if skip is not None else 0}
 
 
 def simulate(netlist_text: str, backend=None) -> dict:

@@ -14,6 +14,25 @@ GOLD = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "forces_group_abort: the test raises the group mode's abort word on purpose (relaunches are expected)")
+
+
+@pytest.fixture(autouse=True)
+def _group_mode_stays_healthy(request):
+    """Around EVERY gpu test: no group-mode launch was repeated after a bounded-wait abort and no wait had to be ended by
+    the read-modify-write poll (spicey_amd.lib.GROUP_TOTALS, fed by every handle a test closes) — a silent relaunch must not
+    pass the suite.  The one test that forces aborts is marked `forces_group_abort`."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import gc
+    from spicey_amd import lib
+    before = dict(lib.GROUP_TOTALS)
+    yield
+    gc.collect()  # handles that went out of scope report on close
+    if request.node.get_closest_marker("forces_group_abort") is None:
+        assert lib.GROUP_TOTALS["retries"] == before["retries"], "a group-mode launch was repeated after a bounded-wait abort"
+    assert lib.GROUP_TOTALS["stale_polls"] == before["stale_polls"], "a group-mode wait was ended by the read-modify-write poll only"
 
 
 def load_golden(name):
@@ -55,6 +74,13 @@ SMALL_GOLDENS = ["two_probes", "transient01", "case_insensitive", "switch_vt_vh"
 # the reference's own quirk (solveReal.ts:45: row updates with |multiplier| < 1e-15 are skipped): the oracle reproduces both
 # bit for bit; the sparse static-order path reproduces the second one and, by construction, not the first (test_oracle.py)
 QUIRK_GOLDENS = ["skip_quirk", "skip_quirk_ref"]
+# the same line of the reference in ordinary topologies (round 3): what the reference did on each (oracle counts of NONZERO
+# multipliers its `|f| < EPS` test dropped) and what this build's indicator says (SpiceyOptions.diagnostics bit 0):
+#   name: (reference skipped any?, indicator > 0?)   — neither implies the other: the indicator looks at the STAMPED matrix
+SKIP_CASES = {"skip_quirk": (True, True), "skip_quirk_ref": (False, False), "skip_big_c": (True, True),
+              "skip_switch_roff": (False, True),   # a milliohm resistor cancels out of the pivot the reference ends up with: false alarm
+              "skip_clamp_floor": (True, False)}   # the one skipped multiplier belongs to an UPDATED entry: not seen, and harmless
+PROBE_GOLDENS = ["probe_unmatched"]
 SINGULAR_GOLDENS = ["err_singular", "err_vloop", "near_sing_b", "near_sing_d", "near_sing_f"]
 LARGE_GOLDENS = ["rc1000_200", "dchain1000_200", "mesh20_30"]
 

@@ -29,7 +29,30 @@ def main():
         src_np = abi.source_table(ckt, dt, steps)
     src = sdist.broadcast_f64(src_np).numpy()
     mine = sdist.shard_range(n_total)
-    flat, dt, steps, _ = synth.chain_batch("diode_chain", 24, [i + 1 for i in mine], tran=tran)
+    # rank 0 holds the parsed batch (every instance); the others get the topology by broadcast and their block of the
+    # per-instance values by scatter (spicey_amd/dist.py) — and must end up with what they would have built
+    full = None
+    if r == 0:
+        full, _, _, _ = synth.chain_batch("diode_chain", 24, range(1, n_total + 1), tran=tran)
+        full.C_vprev[:] = np.arange(n_total)[:, None] * 1e-3  # (state travels too)
+    topo = sdist.broadcast_topology(full)
+    flat = sdist.scatter_params_from_root(topo, full, n_total)
+    own, dt, steps, _ = synth.chain_batch("diode_chain", 24, [i + 1 for i in mine], tran=tran)
+    assert flat.n_inst == len(mine) == own.n_inst and flat.n_nodes == own.n_nodes
+    for k in abi.FlatCircuit.TOPO:
+        assert np.array_equal(getattr(flat, k), getattr(own, k)), k
+    for k in abi.FlatCircuit.VALS:
+        if k != "C_vprev":
+            assert np.array_equal(getattr(flat, k), getattr(own, k)), k
+    assert np.array_equal(flat.C_vprev, np.repeat(np.array(list(mine))[:, None] * 1e-3, flat.nC, axis=1))
+    flat.C_vprev[:] = 0.0
+    ids = sdist.assert_distinct_devices(100 + r)
+    assert ids == [100 + i for i in range(w)]
+    try:
+        sdist.assert_distinct_devices(7)
+        raise SystemExit("assert_distinct_devices accepted two ranks on one device")
+    except RuntimeError:
+        pass
     be = EmulBackend(2, 64)
     res = be.run(flat, steps, dt, src)
     assert res["status"] == 0

@@ -144,6 +144,12 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
 }
 }  // namespace
 
+// diagnostics outputs of the NEXT spicey_emul_run (SpiceyOptions.diagnostics of the product): skip-risk counters [n_inst]
+// and per-step linearisation error [n_inst][steps + 1]; both optional, consumed by one run
+static unsigned long long *g_diag_skip = nullptr;
+static double *g_diag_linerr = nullptr;
+extern "C" void spicey_emul_set_diag(unsigned long long *skip_risk, double *lin_err) { g_diag_skip = skip_risk; g_diag_linerr = lin_err; }
+
 extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, int64_t steps, double dt, const double *src,
                                    double *out_v, double *out_i, int32_t *iters, double *C_vprev, double *L_iprev,
                                    double *D_vdprev, int32_t *S_ison, int32_t reverse, SpiceyInfo *info, int32_t *err4,
@@ -201,6 +207,14 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
     R.front_lds_doubles = (reverse & 8) ? 6144 : SPICEY_FRONT_LDS_DOUBLES;  // bit 3: force the staged path for fronts above 64 rows
     if (info) info->tail_levels = P.nFronts;  // (diagnostic: number of fronts)
   }
+  std::vector<double> lin_vd((size_t)ni * (P.nD + 1), 0.0);
+  if (g_diag_skip) { memset(g_diag_skip, 0, sizeof(unsigned long long) * (size_t)ni); R.skip_risk = g_diag_skip; }
+  if (g_diag_linerr) {
+    memset(g_diag_linerr, 0, sizeof(double) * (size_t)ni * (size_t)(steps + 1));
+    R.lin_err = (unsigned long long *)g_diag_linerr;
+    R.lin_vd = P.nD > 0 ? lin_vd.data() : nullptr;
+  }
+  g_diag_skip = nullptr; g_diag_linerr = nullptr;
   if (T <= 0 || (T & 63)) return SPICEY_ERR_BAD_DESC;
   if ((reverse & 4) && T < 128) return SPICEY_ERR_BAD_DESC;  // the chain runs on T / 2 threads: at least one wave
   if (rmax > 16 || (rmax >= 0 && (!P.has16 || K > 2))) return SPICEY_ERR_BAD_DESC;  // v2 supports K <= 2

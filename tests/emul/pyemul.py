@@ -47,7 +47,7 @@ def _p(a, t):
 
 
 class EmulBackend:
-    def __init__(self, K=1, T=256, reverse=False, rmax=-1, no_reuse=False, chain=False, front_cut=0, stage_fronts=False, ac_resident=False, no_pcr=False, no_rows=False, ac_no_dense=False, virt_wgs=1):
+    def __init__(self, K=1, T=256, reverse=False, rmax=-1, no_reuse=False, chain=False, front_cut=0, stage_fronts=False, ac_resident=False, no_pcr=False, no_rows=False, ac_no_dense=False, virt_wgs=1, diagnostics=0):
         """rmax < 0: v1 interpreter (sliced-ELL, 32-bit); rmax >= 0: v2 with `rmax` register-resident slots.
         no_reuse: refactor every step even when the circuit is linear."""
         self.K, self.T, self.reverse, self.rmax, self.no_reuse = K, T, reverse, rmax, no_reuse
@@ -59,6 +59,7 @@ class EmulBackend:
         self.stage_fronts = stage_fronts  # dense fronts above 64 rows take the panel-staging (global workspace) path
         assert virt_wgs in (1, 3, 7, 21)
         self.virt_wgs = virt_wgs  # the subtree-local levels below a front cut are played as this many workgroups, one after the other
+        self.diagnostics = diagnostics  # bit 0: skip-risk counters, bit 1: per-step linearisation error (SpiceyOptions.diagnostics)
         self.front_cut = front_cut  # v1 only: pivots of elimination-tree level >= front_cut are factored as dense fronts
         self.info = None
         self.solves = None
@@ -77,6 +78,11 @@ class EmulBackend:
         info = abi.SpiceyInfo()
         err4 = np.zeros(4, np.int32)
         solves = C.c_int64(0)
+        skip = np.zeros(ni, np.uint64) if self.diagnostics & 1 else None
+        linerr = np.zeros((ni, steps + 1)) if self.diagnostics & 2 else None
+        L.spicey_emul_set_diag.restype = None
+        L.spicey_emul_set_diag.argtypes = [C.c_void_p, C.c_void_p]
+        L.spicey_emul_set_diag(skip.ctypes.data if skip is not None else None, linerr.ctypes.data if linerr is not None else None)
         rc = L.spicey_emul_run(C.byref(d), self.K, self.T, steps, dt, _p(src, C.c_double), _p(out_v, C.c_double),
                                _p(out_i, C.c_double), _p(iters, C.c_int32), _p(st["C_vprev"], C.c_double),
                                _p(st["L_iprev"], C.c_double), _p(st["D_vdprev"], C.c_double), _p(st["S_ison"], C.c_int32),
@@ -84,7 +90,12 @@ class EmulBackend:
         self.info = info.as_dict()
         self.solves = solves.value
         detail = f"singular at inst {err4[1]} step {err4[2]} iter {err4[3]}" if rc == abi.ERR_SINGULAR else ""
-        return {"status": rc, "detail": detail, "out_v": out_v, "out_i": out_i, "iters": iters, "state": st}
+        res = {"status": rc, "detail": detail, "out_v": out_v, "out_i": out_i, "iters": iters, "state": st}
+        if skip is not None:
+            res["skip_risk"] = skip.astype(np.int64)
+        if linerr is not None:
+            res["lin_err"] = linerr
+        return res
 
 
     def run_ac(self, flat: abi.FlatCircuit, freqs, vph, want_currents: bool = True) -> dict:

@@ -8,7 +8,7 @@ Integer results (iteration counts, switch states) must be identical.
 import numpy as np
 import pytest
 
-from conftest import LARGE_GOLDENS, SINGULAR_GOLDENS, SMALL_GOLDENS, farr, golden_netlist, load_golden
+from conftest import LARGE_GOLDENS, SINGULAR_GOLDENS, SKIP_CASES, SMALL_GOLDENS, farr, golden_netlist, load_golden
 from spicey_amd import abi, synth
 from spicey_amd.netlist import parseNetlist
 
@@ -106,7 +106,7 @@ def test_public_api_default_backend():
 
 @pytest.mark.parametrize("K,T,force_global,interp", [(1, 64, False, 1), (1, 1024, False, 1), (2, 256, False, 1), (4, 256, False, 1),
                                                      (1, 256, True, 1), (2, 512, True, 1), (1, 64, False, 2), (1, 1024, False, 2),
-                                                     (1, 256, False, 2), (1, 512, False, 2), (2, 256, False, 2), (2, 128, False, 2)])
+                                                     (1, 256, False, 2), (1, 512, False, 2), (1, 128, False, 2)])
 def test_geometry_variants_batched(K, T, force_global, interp, oracle_backend):
     """Instance batches (config 4 shape, small): every (instances/workgroup, threads, LDS|global) variant."""
     from spicey_amd.lib import HipBackend
@@ -126,6 +126,12 @@ def test_geometry_variants_batched(K, T, force_global, interp, oracle_backend):
     assert tol_ratio(got["out_v"], ref["out_v"]).max() <= 1.0
     assert tol_ratio(got["out_i"], ref["out_i"]).max() <= 1.0
     assert got["solves"] == 7 * (steps + 1)
+    if K == 2 and not force_global:
+        # the register-resident interpreter is built for one instance per workgroup only (its K = 2 build spilled vector
+        # registers, which the build refuses): asking for both is a descriptor error, not a silent fallback
+        from spicey_amd.lib import SpiceyNativeError
+        with pytest.raises(SpiceyNativeError, match="inst_per_wg = 1"):
+            HipBackend(threads=T, inst_per_wg=2, interpreter=2).run(batch, steps, dt, src)
 
 
 def test_probe_filter_and_no_currents(oracle_backend):
@@ -253,33 +259,46 @@ def test_group_mode_workgroups_cooperate_on_one_instance(oracle_backend):
     assert np.array_equal(got2["out_v"][0], first["out_v"][0]) and np.array_equal(got2["out_v"][1], first["out_v"][0])
 
 
-def test_group_mode_abort_is_repeated_once(monkeypatch, capfd):
-    """Every cross-workgroup wait of the group mode is a bounded spin; a launch whose spin runs out aborts as a whole and
-    spicey_sync repeats it ONCE from the state it started with (include/spicey_hip.h).  The test raises the abort word at
-    the start of every first attempt: two consecutive runs (the second continues from the first one's state), with dense
-    fronts and without, must give the bits, the final state and the solve counts of undisturbed runs."""
+@pytest.mark.forces_group_abort
+def test_group_mode_abort_is_reported_and_repeated_on_request(monkeypatch, capfd):
+    """Every cross-workgroup wait of the group mode is bounded in time; a launch whose wait runs out aborts as a whole.
+    By default that is SPICEY_ERR_HIP with the waiter's position in the error text; with SpiceyOptions.group_retry the launch
+    is repeated ONCE from the state it started with (include/spicey_hip.h) and the text of the aborted attempt stays
+    readable.  The test raises the abort word at the start of every first attempt: two consecutive runs (the second
+    continues from the first one's state), with dense fronts and without, must give the bits, the final state and the
+    solve counts of undisturbed runs."""
     from spicey_amd.lib import Handle
     ckt = parseNetlist(synth.rcd_mesh(20, seed=8, tran=".tran 1e-6 1e-5"))
     dt, steps = abi.computeEffectiveTimeStep(1e-6, 1e-5)
     flat = abi.flatten(ckt)
     src = abi.source_table(ckt, dt, steps)
     for kw in (dict(force_global=True, wgs_per_inst=4), dict(force_global=True, wgs_per_inst=7, front_cut=3)):
+        # default: no relaunch, the abort is the caller's to see
+        monkeypatch.setenv("SPICEY_TEST_FORCE_GROUP_ABORT", "1")
+        h = Handle(flat, **kw)
+        try:
+            r = h.run(steps, dt, src)
+            assert r["status"] == abi.ERR_HIP and "cross-workgroup wait timed out" in r["detail"] and "abort word raised" in r["detail"], r["detail"]
+            assert h.group_retries() == 0
+        finally:
+            h.close()
         outs = {}
         for forced in (False, True):
             if forced:
                 monkeypatch.setenv("SPICEY_TEST_FORCE_GROUP_ABORT", "1")
             else:
                 monkeypatch.delenv("SPICEY_TEST_FORCE_GROUP_ABORT", raising=False)
-            h = Handle(flat, **kw)
+            h = Handle(flat, group_retry=True, **kw)
             try:
                 a = h.run(steps, dt, src)
                 b = h.run(steps, dt, src)  # continues from the state the first run left
                 assert a["status"] == 0 and b["status"] == 0, (kw, forced, a["detail"], b["detail"])
-                outs[forced] = (a, b, h.state(), h.group_retries())
+                outs[forced] = (a, b, h.state(), h.group_retries(), h.error())
             finally:
                 h.close()
         monkeypatch.delenv("SPICEY_TEST_FORCE_GROUP_ABORT", raising=False)
         assert outs[False][3] == 0 and outs[True][3] == 2
+        assert outs[False][4] == "" and outs[True][4].startswith("recovered: cross-workgroup wait timed out")
         for i in (0, 1):
             assert np.array_equal(outs[True][i]["out_v"], outs[False][i]["out_v"]) and np.array_equal(outs[True][i]["out_i"], outs[False][i]["out_i"])
             assert np.array_equal(outs[True][i]["iters"], outs[False][i]["iters"]) and outs[True][i]["solves"] == outs[False][i]["solves"]
@@ -287,6 +306,66 @@ def test_group_mode_abort_is_repeated_once(monkeypatch, capfd):
         for k in outs[False][2]:
             assert np.array_equal(outs[True][2][k], outs[False][2][k]), k
     assert "repeating the launch once" in capfd.readouterr().err
+
+
+def test_group_mode_launches_of_several_handles_share_one_device(oracle_backend):
+    """Launch admission (include/spicey_hip.h): group-mode launches need all their workgroups resident, so the library lets
+    only one of them run on a device at a time, whatever handles and host threads they come from.  Three shards on device
+    0, each a group of 64 workgroups with dense fronts (3 x 64 workgroups of 152 KB LDS would otherwise ask for 192 CUs
+    at once while each waits for its missing ones), launched from three host threads by spicey_run_multi; and a
+    register-resident batch launched between two group launches from the same thread without synchronising."""
+    import torch
+    from spicey_amd.lib import Handle, MultiHandle
+    ckt = parseNetlist(synth.rcd_mesh(30, seed=4, tran=".tran 1e-6 1.2e-5"))
+    dt, steps = abi.computeEffectiveTimeStep(1e-6, 1.2e-5)
+    flat1 = abi.flatten(ckt)
+    src = abi.source_table(ckt, dt, steps)
+    ref = oracle_backend.run(flat1, steps, dt, src)
+    one = Handle(flat1, force_global=True, wgs_per_inst=64, front_cut=5)
+    try:
+        a = one.run(steps, dt, src)
+        assert a["status"] == 0 and one.info()["wgs_per_inst"] == 64 and one.info()["n_fronts"] > 0
+        assert tol_ratio(a["out_v"], ref["out_v"]).max() <= 1.0
+        assert one.group_retries() == 0 and one.group_stale_polls() == 0
+    finally:
+        one.close()
+    m = MultiHandle(flat1.replicate(3), [0, 0, 0], force_global=1, wgs_per_inst=64, front_cut=5)
+    try:
+        assert [s["info"]["wgs_per_inst"] for s in m.shards()] == [64, 64, 64]
+        for _ in range(3):
+            r = m.run(steps, dt, src)
+            assert r["status"] == 0, r["detail"]
+            for k in range(3):
+                assert np.array_equal(r["out_v"][k], a["out_v"][0]) and np.array_equal(r["out_i"][k], a["out_i"][0])
+        assert m.group_retries() == 0 and m.group_stale_polls() == 0
+    finally:
+        m.close()
+    # one thread, three launches in flight on three streams: group, register-resident batch, group
+    dev = torch.device("cuda:0")
+    ck2 = parseNetlist(synth.diode_chain(200, seed=3, tran=".tran 1e-6 1.2e-5"))
+    flat2 = abi.flatten(ck2).replicate(300)
+    src2 = abi.source_table(ck2, dt, steps)
+    g1, g2 = Handle(flat1, force_global=True, wgs_per_inst=64, front_cut=5), Handle(flat1, force_global=True, wgs_per_inst=32, front_cut=5)
+    b = Handle(flat2)
+    try:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        d_src = torch.tensor(src, device=dev)
+        d_src2 = torch.tensor(src2, device=dev)
+        outs = [torch.zeros((1, steps + 1, flat1.n_out), dtype=torch.float64, device=dev) for _ in range(2)]
+        out_b = torch.zeros((300, steps + 1, flat2.n_out), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        g1.run_device(steps, dt, d_src.data_ptr(), outs[0].data_ptr(), stream=streams[0].cuda_stream)
+        b.run_device(steps, dt, d_src2.data_ptr(), out_b.data_ptr(), stream=streams[1].cuda_stream)
+        g2.run_device(steps, dt, d_src.data_ptr(), outs[1].data_ptr(), stream=streams[2].cuda_stream)
+        assert g2.sync() == 0 and b.sync() == 0 and g1.sync() == 0, (g1.error(), b.error(), g2.error())
+        torch.cuda.synchronize()
+        for o in outs:
+            assert np.array_equal(o.cpu().numpy(), a["out_v"])
+        refb = oracle_backend.run(abi.flatten(ck2), steps, dt, src2)
+        assert tol_ratio(out_b.cpu().numpy()[[0, 299]], np.repeat(refb["out_v"], 2, axis=0)).max() <= 1.0
+        assert g1.group_retries() == g2.group_retries() == 0 and g1.group_stale_polls() == g2.group_stale_polls() == 0
+    finally:
+        g1.close(); g2.close(); b.close()
 
 
 def test_config5_full_size_mesh(oracle_backend):
@@ -709,3 +788,110 @@ def test_reference_skip_quirk_on_gpu(oracle_backend):
     assert tol_ratio(got_r["out_v"], ref_r["out_v"]).max() <= 1.0
     assert tol_ratio(got_q["out_v"][0, :, :2], ref_q["out_v"][0, :, :2]).max() <= 1.0
     assert tol_ratio(got_q["out_v"][0, 1:, 2], ref_q["out_v"][0, 1:, 2]).min() > 50.0
+    # ... and the caller is told: the indicator of spicey_last_skip_risk is up on the circuit where the reference skips,
+    # down on its twin, and the result is the reference's algorithm without that one line
+    from oracle.pyoracle import OracleBackend
+    for interp in (1, 2):
+        dq = HipBackend(diagnostics=1, interpreter=interp).run(fq, steps, dt, src)
+        dr = HipBackend(diagnostics=1, interpreter=interp).run(fr, steps_r, dt_r, src_r)
+        assert dq["skip_risk"][0] > 0 and dr["skip_risk"][0] == 0
+        assert np.array_equal(dq["out_v"], got_q["out_v"]) or interp == 1
+    nos = OracleBackend(skip_off=True).run(fq, steps, dt, src)
+    assert tol_ratio(got_q["out_v"], nos["out_v"]).max() <= 1.0
+
+
+@pytest.mark.parametrize("name", sorted(SKIP_CASES))
+def test_skip_risk_indicator_on_gpu(name, oracle_backend):
+    """SpiceyOptions.diagnostics bit 0 on the device (CPU twin: test_program_emul.py): the indicator is up exactly on the
+    cases listed in conftest.SKIP_CASES, in both interpreters; and wherever the reference skips, the GPU result is the
+    reference's algorithm WITHOUT `if (Math.abs(f) < EPS) continue` (solveReal.ts:45) within the 1e-9 bar."""
+    from oracle.pyoracle import OracleBackend
+    from spicey_amd.lib import HipBackend
+    ckt = parseNetlist(golden_netlist(load_golden(name)))
+    dt, steps = abi.computeEffectiveTimeStep(ckt.analyses["tran"]["dt"], ckt.analyses["tran"]["tstop"])
+    flat, src = abi.flatten(ckt), abi.source_table(ckt, dt, steps)
+    ref = oracle_backend.run(flat, steps, dt, src)
+    nos = OracleBackend(skip_off=True).run(flat, steps, dt, src)
+    assert (ref["skipped"][0] > 0) == SKIP_CASES[name][0]
+    gmax = max(1.0, float((1.0 / flat.R_val).max()))
+    for kw in (dict(interpreter=1), dict(interpreter=2), dict(force_global=True)):
+        got = HipBackend(diagnostics=1, **kw).run(flat, steps, dt, src)
+        assert got["status"] == 0 and np.array_equal(got["iters"], ref["iters"])
+        assert (got["skip_risk"][0] > 0) == SKIP_CASES[name][1], (name, kw, got["skip_risk"])
+        assert tol_ratio(got["out_v"], nos["out_v"]).max() <= 1.0
+        fin = np.isfinite(nos["out_i"])
+        assert (np.abs(got["out_i"] - nos["out_i"])[fin] <= (1e-9 * np.abs(nos["out_i"]) + 1e-12 * gmax)[fin]).all()
+        if tol_ratio(got["out_v"], ref["out_v"]).max() > 1.0:
+            assert got["skip_risk"][0] > 0 and ref["skipped"][0] > 0
+
+
+def test_diagnostics_on_gpu_change_nothing_and_match_the_oracle(oracle_backend):
+    """Both diagnostics on (skip-risk counters, per-step linearisation error): no bit of any result, state or iteration
+    count moves; the indicator stays 0 on every small golden; the linearisation error is the oracle's (the reference's own
+    quantities: max over the diodes of |vd(x) - vd the step's last solve was stamped with|, simulateTRAN.ts:81-85) — single
+    circuits through both interpreters, a batch, and a mesh on cooperating workgroups with dense fronts."""
+    from spicey_amd.lib import HipBackend
+    def lin_ok(got, ref):
+        return (np.abs(got - ref) <= 1e-9 * np.abs(ref) + 1e-11).all()
+    for name in SMALL_GOLDENS:
+        ckt = parseNetlist(golden_netlist(load_golden(name)))
+        dt, steps = abi.computeEffectiveTimeStep(ckt.analyses["tran"]["dt"], ckt.analyses["tran"]["tstop"])
+        flat, src = abi.flatten(ckt), abi.source_table(ckt, dt, steps)
+        ref = oracle_backend.run(flat, steps, dt, src)
+        for kw in ((dict(), dict(interpreter=1)) if name in ("dchain20", "boost_probe", "half_bridge", "mesh6", "switch_vt_vh") else (dict(),)):
+            off = HipBackend(**kw).run(flat, steps, dt, src)
+            on = HipBackend(diagnostics=3, **kw).run(flat, steps, dt, src)
+            assert on["status"] == 0 and on["skip_risk"][0] == 0, name
+            for k in ("out_v", "out_i", "iters"):
+                assert np.array_equal(on[k], off[k], equal_nan=(k != "iters")), (name, k)
+            for k in off["state"]:
+                assert np.array_equal(on["state"][k], off["state"][k]), (name, k)
+            if name != "bridge_rectifier":
+                assert lin_ok(on["lin_err"], ref["lin_err"]), name
+    # a batch of seven distinct diode chains: one value per instance and step
+    flats = [abi.flatten(parseNetlist(synth.diode_chain(40, seed=s, tran=".tran 1e-6 3e-5"))) for s in range(1, 8)]
+    batch = abi.stack_instances(flats)
+    dt, steps = abi.computeEffectiveTimeStep(1e-6, 3e-5)
+    src = abi.source_table(parseNetlist(synth.diode_chain(40, seed=1, tran=".tran 1e-6 3e-5")), dt, steps)
+    ref = oracle_backend.run(batch, steps, dt, src)
+    for kw in (dict(), dict(interpreter=1, inst_per_wg=2), dict(threads=256)):
+        on = HipBackend(diagnostics=3, **kw).run(batch, steps, dt, src)
+        assert on["status"] == 0 and (on["skip_risk"] == 0).all() and lin_ok(on["lin_err"], ref["lin_err"]), kw
+        assert ref["lin_err"].max() > 1.0  # (the front of the pulse moves every junction by volts per step)
+    # a mesh on 4 cooperating workgroups with dense fronts
+    ckt = parseNetlist(synth.rcd_mesh(20, seed=8, tran=".tran 1e-6 1e-5"))
+    dt, steps = abi.computeEffectiveTimeStep(1e-6, 1e-5)
+    flat, src = abi.flatten(ckt), abi.source_table(ckt, dt, steps)
+    ref = oracle_backend.run(flat, steps, dt, src)
+    for kw in (dict(force_global=True, wgs_per_inst=4, front_cut=3), dict(force_global=True, wgs_per_inst=4)):
+        off = HipBackend(**kw).run(flat, steps, dt, src)
+        on = HipBackend(diagnostics=3, **kw).run(flat, steps, dt, src)
+        assert on["status"] == 0 and on["skip_risk"][0] == 0 and np.array_equal(on["out_v"], off["out_v"]) and np.array_equal(on["iters"], off["iters"])
+        assert lin_ok(on["lin_err"], ref["lin_err"]), kw
+
+
+def test_readme_rc_config1_on_gpu(oracle_backend):
+    """BASELINE configs[0]: the README's RC low-pass (v1 / r1 / c1) with `.tran 1us 10ms` = 10 001 points, 3 unknowns; the
+    source is `dc 0`, so every voltage and current is exactly 0 — on the HIP path too, through the public API."""
+    from spicey_amd.simulate import simulate
+    g = load_golden("readme_rc")
+    res = simulate(golden_netlist(g))
+    run = g["runs"][0]
+    tran = res["tran"]
+    assert len(tran["times"]) == run["npoints"] == 10001 and list(tran["nodeVoltages"]) == run["keysV"] and list(tran["elementCurrents"]) == run["keysI"]
+    assert [tran["times"][0], tran["times"][1], tran["times"][-1]] == run["times_first_last"]
+    assert all(v == 0.0 for k in run["keysV"] for v in tran["nodeVoltages"][k])
+    assert all(v == 0.0 for k in run["keysI"] for v in tran["elementCurrents"][k])
+    assert (np.asarray(tran["iterations"]) == 1).all() and tran["skipRisk"] == 0
+    assert [c.vPrev for c in res["circuit"].C] == run["state"]["C_vPrev"]
+
+
+def test_unmatched_probes_on_gpu():
+    """`.PRINT TRAN` names that match no node (reference-generated golden): nodeVoltages = {}, currents as usual."""
+    from spicey_amd.simulate import simulate
+    g = load_golden("probe_unmatched")
+    tran = simulate(golden_netlist(g))["tran"]
+    run = g["runs"][0]
+    assert tran["nodeVoltages"] == {} and list(tran["elementCurrents"]) == run["keysI"]
+    for k in run["keysI"]:
+        assert tol_ratio(np.asarray(tran["elementCurrents"][k]), farr(run["I"][k])).max() <= 1.0

@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import LARGE_GOLDENS, REPO, SINGULAR_GOLDENS, SMALL_GOLDENS, golden_netlist, load_golden
+from conftest import LARGE_GOLDENS, REPO, SINGULAR_GOLDENS, SKIP_CASES, SMALL_GOLDENS, golden_netlist, load_golden
 from emul.pyemul import EmulBackend, symbolic
 from spicey_amd import abi, synth
 from spicey_amd.netlist import parseNetlist
@@ -74,6 +74,64 @@ def test_reference_skips_tiny_multipliers_and_the_sparse_path_cannot(oracle_back
         assert ratio(got_r["out_v"], ref_r["out_v"]).max() <= 1.0                            # parity where the reference does not skip
         assert ratio(got_q["out_v"][0, :, :2], ref_q["out_v"][0, :, :2]).max() <= 1.0        # a, b: parity
         assert ratio(got_q["out_v"][0, 1:, c], ref_q["out_v"][0, 1:, c]).min() > 50.0        # c: the documented difference
+
+
+@pytest.mark.parametrize("name", sorted(SKIP_CASES))
+def test_skip_risk_indicator_on_the_skip_cases(name, oracle_backend):
+    """SpiceyOptions.diagnostics bit 0 (include/spicey_hip.h, spicey_last_skip_risk): the device counts the (solve, column)
+    pairs whose STAMPED matrix column holds a nonzero entry below 1e-15 x the column's largest — the first-order sign that
+    the reference's `|f| < EPS` skip (solveReal.ts:45) dropped a row update this build performs.  Wherever the reference
+    skips, this build agrees within the 1e-9 bar with the reference's algorithm run WITHOUT that line (the oracle's test
+    knob): the skip is the whole difference."""
+    from oracle.pyoracle import OracleBackend
+    flat, steps, dt, src = _inputs(name)
+    ref = oracle_backend.run(flat, steps, dt, src)
+    nos = OracleBackend(skip_off=True).run(flat, steps, dt, src)
+    for rmax in (-1, 8):
+        got = EmulBackend(1, 64, False, rmax, diagnostics=1).run(flat, steps, dt, src)
+        assert got["status"] == 0 and np.array_equal(got["iters"], ref["iters"])
+        assert (got["skip_risk"][0] > 0) == SKIP_CASES[name][1], (name, rmax, got["skip_risk"])
+        # (currents: the absolute floor scales with the largest conductance — the current of a 0.1 milliohm resistor is 1e4 S
+        # times a difference of two voltages that agree to rounding)
+        gmax = max(1.0, float((1.0 / flat.R_val).max()))
+        assert ratio(got["out_v"], nos["out_v"]).max() <= 1.0
+        assert (np.abs(got["out_i"] - nos["out_i"]) <= RTOL * np.abs(nos["out_i"]) + ATOL * gmax)[np.isfinite(nos["out_i"])].all()
+        if ratio(got["out_v"], ref["out_v"]).max() > 1.0:  # beyond the bar against the reference as it is: only with the indicator up
+            assert got["skip_risk"][0] > 0 and ref["skipped"][0] > 0
+
+
+def test_skip_risk_is_zero_on_every_small_golden_and_diagnostics_change_nothing(oracle_backend):
+    """The indicator stays 0 on the reference's own test circuits and the stress netlists, and switching the diagnostics on
+    changes no bit of the results, states and iteration counts; the per-step linearisation error (diagnostics bit 1) is the
+    quantity the oracle computes in the reference's own terms (max over the diodes of |vd(x) - vd the last solve was
+    stamped with|, simulateTRAN.ts:81-85)."""
+    for name in SMALL_GOLDENS:
+        flat, steps, dt, src = _inputs(name)
+        ref = oracle_backend.run(flat, steps, dt, src)
+        for rmax in ((-1, 8) if name in ("dchain20", "boost_probe", "half_bridge", "mesh6", "switch_vt_vh") else (-1,)):
+            off = EmulBackend(1, 64, False, rmax).run(flat, steps, dt, src)
+            on = EmulBackend(1, 64, False, rmax, diagnostics=3).run(flat, steps, dt, src)
+            assert on["status"] == 0 and on["skip_risk"][0] == 0, name
+            for k in ("out_v", "out_i", "iters"):
+                assert np.array_equal(on[k], off[k], equal_nan=(k != "iters")), (name, k)
+            for k in off["state"]:
+                assert np.array_equal(on["state"][k], off["state"][k]), (name, k)
+            if name not in LOOSE:  # (the ill-conditioned bridge moves by millivolts under rounding: no 1e-9 statement there)
+                assert (np.abs(on["lin_err"] - ref["lin_err"]) <= 1e-9 * np.abs(ref["lin_err"]) + 1e-11).all(), name
+
+
+def test_skip_risk_of_a_linear_circuit_counts_every_solve(oracle_backend):
+    """A circuit without diodes and switches reuses its factors: its stamped matrix is looked at once, at step 0, and the
+    count stands for all its solves — the same number as with refactoring every step."""
+    text = "* a 1e-16 S leak next to 1 S\nV1 a 0 dc 1\nR1 a b 1\nR2 b c 1e16\nR3 c 0 1k\nC1 c 0 1n\n.tran 1e-6 5e-6\n.end\n"
+    ckt = parseNetlist(text)
+    dt, steps = abi.computeEffectiveTimeStep(ckt.analyses["tran"]["dt"], ckt.analyses["tran"]["tstop"])
+    flat, src = abi.flatten(ckt), abi.source_table(ckt, dt, steps)
+    for rmax in (-1, 8):
+        a = EmulBackend(1, 64, False, rmax, diagnostics=1).run(flat, steps, dt, src)
+        b = EmulBackend(1, 64, False, rmax, no_reuse=True, diagnostics=1).run(flat, steps, dt, src)
+        assert a["status"] == 0 and a["skip_risk"][0] == b["skip_risk"][0] > 0 and a["skip_risk"][0] % (steps + 1) == 0
+        assert np.array_equal(a["out_v"], b["out_v"])
 
 
 def test_bridge_rectifier_reference_is_ill_conditioned(oracle_backend):

@@ -39,6 +39,9 @@ SMALL = {
     "near_sing_a": 1, "near_sing_b": 1, "near_sing_c": 1, "near_sing_d": 1, "near_sing_e": 1, "near_sing_f": 1,
     # solveReal.ts:45 skips row updates with |multiplier| < 1e-15: a diode between two SOURCE nodes changes a node voltage
     "skip_quirk": 1, "skip_quirk_ref": 1,
+    # the same skip in ordinary topologies: a clamped diode next to a floored one, an open switch (1/Roff) behind a milliohm
+    # resistor, a floored diode on a node with C/dt = 1e6 S — and .PRINT names that match no node
+    "skip_clamp_floor": 1, "skip_switch_roff": 1, "skip_big_c": 1, "probe_unmatched": 1,
 }
 # name -> generator spec
 SYNTH = {

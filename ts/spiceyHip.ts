@@ -11,7 +11,7 @@
 import { dlopen, FFIType, ptr, CString, type Pointer } from "bun:ffi"
 import { SpiceyDescLayout, SpiceyOptionsLayout } from "./abiLayout"
 
-export const SPICEY_ABI_VERSION = 1
+export const SPICEY_ABI_VERSION = 2
 export const SPICEY_OK = 0
 export const SPICEY_ERR_SINGULAR = 1
 export const SPICEY_ERR_BAD_DESC = 2
