@@ -16,6 +16,18 @@ const main = async () => {
     const { simulateAC } = await import(pathToFileURL(path.join(erased, "simulateAC.mjs")).href)
     const { nativeVersion } = await import(pathToFileURL(path.join(erased, "spiceyHip.mjs")).href)
     const j = JSON.parse(fs.readFileSync(cktPath, "utf8"))
+    if (j.netlist != null) {
+      // the whole TypeScript package on its own: text -> ts/parseNetlist.ts -> ts/simulate.ts -> native, then the formatter
+      const { simulate, formatTranResult } = await import(pathToFileURL(path.join(erased, "index.mjs")).href)
+      const r = simulate(j.netlist)
+      const enc = (x) => (Number.isFinite(x) ? x : String(x))
+      out.full = { nodes: r.circuit.nodes.rev, times: r.tran.times, keysV: Object.keys(r.tran.nodeVoltages), keysI: Object.keys(r.tran.elementCurrents),
+                   V: r.tran.nodeVoltages, I: {}, skipRisk: r.tran.skipRisk, text_head: formatTranResult(r.tran).split("\n").slice(0, 4),
+                   state: { vPrev: r.circuit.C.map((c) => c.vPrev), iPrev: r.circuit.L.map((l) => l.iPrev), vdPrev: r.circuit.D.map((d) => d.vdPrev), isOn: r.circuit.S.map((s) => s.isOn) } }
+      for (const k of out.full.keysI) out.full.I[k] = r.tran.elementCurrents[k].map(enc)
+      fs.writeFileSync(outPath, JSON.stringify(out))
+      return
+    }
     const ckt = {
       nodes: { rev: j.nodes, count: () => j.nodes.length },
       R: j.R, C: j.C, L: j.L, S: j.S, D: j.D,

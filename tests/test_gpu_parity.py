@@ -329,17 +329,17 @@ def test_group_mode_launches_of_several_handles_share_one_device(oracle_backend)
         assert one.group_retries() == 0 and one.group_stale_polls() == 0
     finally:
         one.close()
-    m = MultiHandle(flat1.replicate(3), [0, 0, 0], force_global=1, wgs_per_inst=64, front_cut=5)
-    try:
-        assert [s["info"]["wgs_per_inst"] for s in m.shards()] == [64, 64, 64]
-        for _ in range(3):
+    for _ in range(3):  # (a fresh handle each time: a second run of one handle continues from the first one's state)
+        m = MultiHandle(flat1.replicate(3), [0, 0, 0], force_global=1, wgs_per_inst=64, front_cut=5)
+        try:
+            assert [s["info"]["wgs_per_inst"] for s in m.shards()] == [64, 64, 64]
             r = m.run(steps, dt, src)
             assert r["status"] == 0, r["detail"]
             for k in range(3):
                 assert np.array_equal(r["out_v"][k], a["out_v"][0]) and np.array_equal(r["out_i"][k], a["out_i"][0])
-        assert m.group_retries() == 0 and m.group_stale_polls() == 0
-    finally:
-        m.close()
+            assert m.group_retries() == 0 and m.group_stale_polls() == 0
+        finally:
+            m.close()
     # one thread, three launches in flight on three streams: group, register-resident batch, group
     dev = torch.device("cuda:0")
     ck2 = parseNetlist(synth.diode_chain(200, seed=3, tran=".tran 1e-6 1.2e-5"))

@@ -101,6 +101,38 @@ def test_ts_layer_matches_python_layer_on_gpu(name, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["two_probes", "boost_probe", "vswitch_pwl", "half_bridge", "skip_quirk", "probe_unmatched"])
+def test_ts_package_on_its_own_from_netlist_text_on_gpu(name, tmp_path):
+    """The whole TypeScript package with nothing of the reference underneath: netlist text -> ts/parseNetlist.ts ->
+    ts/simulate.ts -> libspicey_hip.so -> ts/format.ts, against the Python layer on the same library (bit-identical) and
+    against the reference-generated golden (1e-9 bar; `skip_quirk`: the documented exception, announced by skipRisk > 0)."""
+    from conftest import farr, load_golden
+    from spicey_amd.simulate import formatTranResult, simulate
+    erased, libpath = _prepare(tmp_path)
+    text = open(os.path.join(GOLD, "netlists", name + ".cir")).read()
+    out = _run(erased, libpath, tmp_path, {"netlist": text})
+    assert "error" not in out, out
+    t = out["full"]
+    ref = simulate(text)
+    assert t["nodes"] == ref["circuit"].nodes.rev
+    assert t["keysV"] == list(ref["tran"]["nodeVoltages"]) and t["keysI"] == list(ref["tran"]["elementCurrents"]) and t["times"] == ref["tran"]["times"]
+    for k in t["keysV"]:
+        assert np.array_equal(np.array(t["V"][k]), np.array(ref["tran"]["nodeVoltages"][k])), k
+    for k in t["keysI"]:
+        assert np.array_equal(np.array([float(x) for x in t["I"][k]]), np.array(ref["tran"]["elementCurrents"][k], dtype=np.float64), equal_nan=True), k
+    assert t["skipRisk"] == ref["tran"]["skipRisk"] and (t["skipRisk"] > 0) == (name == "skip_quirk")
+    assert t["text_head"] == formatTranResult(ref["tran"]).split("\n")[:4]
+    assert t["state"]["vPrev"] == [c.vPrev for c in ref["circuit"].C] and t["state"]["isOn"] == [s.isOn for s in ref["circuit"].S]
+    g = load_golden(name)["runs"][0]
+    assert t["keysV"] == g["keysV"] and t["keysI"] == g["keysI"] and t["times"] == g["times"]
+    if name != "skip_quirk":
+        for k in g["keysV"]:
+            a, b = np.array(t["V"][k]), farr(g["V"][k])
+            assert (np.abs(a - b) <= 1e-9 * np.abs(b) + 1e-12).all(), k
+        assert t["text_head"] == g["formatted_head"]
+
+
+@pytest.mark.gpu
 def test_ts_ac_layer_matches_python_layer_on_gpu(tmp_path):
     from spicey_amd import ac as sac
     erased, libpath = _prepare(tmp_path)

@@ -11,8 +11,9 @@ import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-FILES = ["abiLayout.ts", "spiceyHip.ts", "simulateTRAN.ts", "simulateAC.ts"]
-STUBS = {"../lib/constants/EPS": "EPS", "../lib/math/Complex": "Complex", "../lib/utils/logspace": "logspace"}
+FILES = ["abiLayout.ts", "spiceyHip.ts", "simulateTRAN.ts", "simulateAC.ts", "constants.ts", "types.ts", "NodeIndex.ts", "numbers.ts",
+         "waveforms.ts", "parseNetlist.ts", "Complex.ts", "logspace.ts", "format.ts", "simulate.ts", "index.ts"]
+STUBS = {}  # (ts/ is self-contained since round 3: nothing is imported from the reference's lib/ any more)
 
 
 def split_top(s, sep=","):
@@ -67,6 +68,13 @@ def erase(src, stub_dir, shim_path):
         if re.match(r"^import type\b", ln):
             i += 1
             continue
+        if re.match(r"^export type \{", ln):  # `export type { A, B } from "./x"`, possibly over several lines
+            while i < len(lines):
+                done = "}" in lines[i]
+                i += 1
+                if done:
+                    break
+            continue
         if re.match(r"^(export )?type \w+", ln):
             depth = 0
             while i < len(lines):
@@ -77,7 +85,21 @@ def erase(src, stub_dir, shim_path):
             continue
         out.append(ln)
         i += 1
-    s = "\n".join(out)
+    # classes: field declarations go, method signatures lose their parameter and return types
+    out2, in_class = [], False
+    for ln in out:
+        if re.match(r"^(export )?class \w+", ln):
+            in_class = True
+        elif in_class and ln.startswith("}"):
+            in_class = False
+        elif in_class:
+            if re.match(r"^  (?:private |public |readonly )*\w+[?!]?: [^=(){}]+$", ln):
+                continue
+            m = re.match(r"^(  (?:static )?(?!if\b|for\b|while\b|switch\b|catch\b)\w+)\((.*)\)(?:: [^{]+)? \{$", ln)
+            if m:
+                ln = f"{m.group(1)}({strip_param_types(m.group(2))}) {{"
+        out2.append(ln)
+    s = "\n".join(out2)
     s = re.sub(r",\s*type \w+(?=\s*[,}])", "", s)  # `import { a, type B }`
     # function declarations: parameter and return types
     res, pos = "", 0
@@ -97,6 +119,7 @@ def erase(src, stub_dir, shim_path):
     s = re.sub(r"\(([^()]*)\)\s*(?::\s*[\w\[\]<>| ]+?)?\s*=>", arrow, s)
     # variable annotations
     s = re.sub(r"\b(const|let) (\w+): [^=\n]+? =", r"\1 \2 =", s)
+    s = re.sub(r"\blet (\w+): [^=\n;]+$", r"let \1", s, flags=re.M)  # `let x: T` without an initialiser
     # casts
     s = re.sub(r" as unknown as \w+", "", s)
     s = re.sub(r" as (any|const|number|\w+Array)\b", "", s)

@@ -3,10 +3,10 @@
 // What stays in TypeScript is what depends on the JS engine's Math (Math.pow in logspace, Math.cos / Math.sin in
 // Complex.fromPolar) and the argument checks that throw before any arithmetic; every per-frequency complex solve
 // (simulateAC.ts:80-126) is one native call for the whole sweep.
-import { EPS } from "../lib/constants/EPS"
-import { Complex } from "../lib/math/Complex"
-import type { ParsedCircuit } from "../lib/parsing/parseNetlist"
-import { logspace } from "../lib/utils/logspace"
+import { EPS } from "./constants"
+import { Complex } from "./Complex"
+import type { ParsedCircuit } from "./types"
+import { logspace } from "./logspace"
 import { runAcNative, type FlatCircuit } from "./spiceyHip"
 
 function frequencies(ac: NonNullable<ParsedCircuit["analyses"]["ac"]>): number[] {

@@ -1,8 +1,8 @@
 // ts/simulateTRAN.ts — drop-in replacement of lib/analysis/simulateTRAN.ts with the native solver underneath.
 // Same signature, same result shape, same in-place mutation of `ckt` state, same Error messages.
 // Everything the reference does outside its time loop stays here, in the reference's own order.
-import { EPS } from "../lib/constants/EPS"
-import type { ParsedCircuit } from "../lib/parsing/parseNetlist"
+import { EPS } from "./constants"
+import type { ParsedCircuit } from "./types"
 import { runTransientNative, type FlatCircuit } from "./spiceyHip"
 
 /** simulateTRAN.ts:14-19 verbatim semantics: must be the same double operations in the same order. */
@@ -107,7 +107,9 @@ function simulateTRAN(ckt: ParsedCircuit) {
   ckt.D.filter((d) => d.model).forEach((d, i) => (d.vdPrev = res.state.vdPrev[i]!))
   ckt.S.filter((s) => s.model).forEach((s, i) => (s.isOn = res.state.isOn[i] !== 0))
 
-  return { times, nodeVoltages, elementCurrents }
+  // (`skipRisk` is this solver's addition to the reference's three keys: > 0 says that the reference's own row-update skip,
+  // solveReal.ts:45, may have made ITS numbers differ from these — ts/spiceyHip.ts, NativeTranResult.skipRisk)
+  return { times, nodeVoltages, elementCurrents, skipRisk: res.skipRisk }
 }
 
 export { simulateTRAN }

@@ -39,6 +39,8 @@ const { symbols: C } = dlopen(libPath, {
   spicey_destroy_multi: { args: [FFIType.ptr], returns: FFIType.void },
   spicey_last_error: { args: [FFIType.ptr], returns: FFIType.ptr },
   spicey_last_solve_count: { args: [FFIType.ptr], returns: FFIType.i64 },
+  // diagnostics (SpiceyOptions.diagnostics bit 0): solves in which the reference's `|f| < EPS` row-update skip may bite
+  spicey_last_skip_risk: { args: [FFIType.ptr, FFIType.ptr], returns: FFIType.i64 },
   spicey_destroy: { args: [FFIType.ptr], returns: FFIType.void },
   spicey_version: { args: [], returns: FFIType.ptr },
   spicey_ac_create: { args: [FFIType.ptr, FFIType.ptr, FFIType.ptr], returns: FFIType.i32 },
@@ -104,6 +106,9 @@ export type NativeTranResult = {
   outI: Float64Array // [steps+1][nCur], order R, C, L, V, S, D
   iters: Int32Array // [steps+1]
   state: { vPrev: Float64Array; iPrev: Float64Array; vdPrev: Float64Array; isOn: Int32Array }
+  /** (solve, column) pairs in which the stamped matrix had a nonzero entry below 1e-15 x its column's largest: where the
+   *  reference's `if (Math.abs(f) < EPS) continue` (solveReal.ts:45) drops a row update this solver performs; 0 = none */
+  skipRisk: number
 }
 
 /** One transient run on the GPU.  Throws Error("Singular matrix (real)") like solveReal.ts:28. */
@@ -111,6 +116,7 @@ export function runTransientNative(f: FlatCircuit, steps: number, dt: number, sr
   const { buf, keep } = packDesc(f)
   const opt = new ArrayBuffer(SpiceyOptionsLayout.size) // zeros: device 0, auto geometry
   new DataView(opt).setInt32(SpiceyOptionsLayout.fields.want_currents.offset, 1, true)
+  new DataView(opt).setInt32(SpiceyOptionsLayout.fields.diagnostics.offset, 1, true)
   const hOut = new BigUint64Array(1)
   let rc = C.spicey_create(ptr(buf), ptr(opt), ptr(hOut))
   void keep
@@ -132,7 +138,8 @@ export function runTransientNative(f: FlatCircuit, steps: number, dt: number, sr
     rc = C.spicey_get_state(h, state.vPrev.length ? ptr(state.vPrev) : null, state.iPrev.length ? ptr(state.iPrev) : null,
       state.vdPrev.length ? ptr(state.vdPrev) : null, state.isOn.length ? ptr(state.isOn) : null)
     if (rc !== SPICEY_OK) throw new Error(`spicey_get_state failed (${rc}): ${lastError(h)}`)
-    return { outV, outI, iters, state }
+    const skipRisk = Number(C.spicey_last_skip_risk(h, null))
+    return { outV, outI, iters, state, skipRisk }
   } finally {
     C.spicey_destroy(h)
   }
