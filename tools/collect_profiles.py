@@ -44,6 +44,22 @@ bench = last_json_line(os.path.join(SRC, "bench_line.json"))
 shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(DST, f"{rnd}_bench_kernel_stats.csv"))
 shutil.copy(one("ac_stats/**/*kernel_stats.csv"), os.path.join(DST, f"{rnd}_ac_kernel_stats.csv"))
 aclines = [json.loads(l) for l in open(os.path.join(SRC, "ac_probe.json")) if l.startswith("{")]
+# ---- HBM traffic of the AC sweep kernel (resident sweep, 64 instances x 201 frequencies; 3 timed repetitions per run)
+try:
+    fa, kac, keep_fa, _ = counters("ac_fetch", "spicey_ac_kernel")
+    wa, _, keep_wa, _ = counters("ac_write", "spicey_ac_kernel")
+    open(os.path.join(DST, f"{rnd}_ac_pmc_counter_collection.csv"), "w").write("\n".join(keep_fa + keep_wa[1:]) + "\n")
+    for rec_ac in aclines:
+        if rec_ac["inst"] != 64:
+            continue
+        tr = 2.0 * fa["FETCH_SIZE"] * 1024.0 + wa["WRITE_SIZE"] * 1024.0  # per dispatch
+        r = rec_ac["roofline"]
+        r.update(frac_formula=r["frac"], achieved_formula=r["achieved"], traffic=tr, traffic_unit="bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes)",
+                 traffic_bytes_per_solve=tr / rec_ac["solves"], achieved=tr / (rec_ac["kernel_ms"] * 1e-3) / 1e9, kernel=kac)
+        r["frac"] = r["achieved"] / r["peak"]
+        r["compulsory_bytes_per_solve"] = 16 * (1000 + 2000 + 1)  # one complex value per recorded node and element
+except AssertionError as e:
+    print("no AC PMC passes in this profile round:", e)
 json.dump(aclines, open(os.path.join(DST, f"{rnd}_ac_probe.json"), "w"), indent=1)
 
 # ---- HBM traffic of the bench kernel: separate FETCH_SIZE / WRITE_SIZE passes

@@ -45,12 +45,14 @@ h.run_device(steps, dt, src.data_ptr(), out_v.data_ptr(), out_i.data_ptr() if ou
 rc = h.sync()
 wall = time.time() - t0
 assert rc == 0, h.error()
+# group mode health (include/spicey_hip.h): no launch was repeated, no wait had to be ended by the read-modify-write poll
+assert h.group_retries() == 0 and h.group_stale_polls() == 0, (h.group_retries(), h.group_stale_polls(), h.error())
 sps = h.solves() / (h.kernel_ms() / 1e3)
 algo = info["algorithmic_bytes_solve"]  # SURVEY.md §8(d) formula with this build's nnz(L+U): 9.4 MB per solve
 rec = dict(config="BASELINE configs[4]: rcd_mesh(%d), %d timesteps, %d instance(s)" % (args.rows, steps, args.inst), n_var=info["n_var"], nnz_lu=info["nnz_lu"],
            levels=info["n_levels"], wgs_per_inst=info["wgs_per_inst"], threads=info["threads"], n_fronts=info["n_fronts"], front_cut=info["front_cut"],
            max_front=info["max_front"], front_ws_MB=info["front_ws_bytes"] / 1e6, kernel_s=h.kernel_ms() / 1e3, wall_s=wall,
-           ms_per_step=h.kernel_ms() / (steps + 1), solves=h.solves(), solves_per_s=sps,
+           ms_per_step=h.kernel_ms() / (steps + 1), solves=h.solves(), solves_per_s=sps, group_retries=h.group_retries(), group_stale_polls=h.group_stale_polls(),
            roofline={"bound": "hbm", "achieved": algo * sps / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": algo * sps / 8e12,
                      "algorithmic_bytes_per_solve": algo, "roofline_solves_per_s": 8e12 / algo, "traffic": None,
                      "note": "a single instance is a serial recurrence over timesteps (SURVEY fact 4): the step time is the critical path of ONE "

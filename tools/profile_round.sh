@@ -18,6 +18,8 @@ step pmc_write;   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --
 step pmc_sq;      timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-single-instance > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err || exit 1
 step pmc_lds;     timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_lds -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-single-instance > $OUT/pmc_lds.json 2> $OUT/pmc_lds.err || exit 1
 step ac;          timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ac_stats -- python3 tools/ac_probe.py --n 1000 --inst 64 --freqs 201 > $OUT/ac_probe.json 2> $OUT/ac.err || exit 1
+step ac_fetch;    timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/ac_fetch -- python3 tools/ac_probe.py --n 1000 --inst 64 --freqs 201 > $OUT/ac_fetch.json 2> $OUT/ac_fetch.err || exit 1
+step ac_write;    timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/ac_write -- python3 tools/ac_probe.py --n 1000 --inst 64 --freqs 201 > $OUT/ac_write.json 2> $OUT/ac_write.err || exit 1
 fi
 if [ "$PART" = config5 ] || [ "$PART" = all ]; then
 step c5_full;     timeout -k 10 900 python3 tools/config5_full.py > $OUT/config5_full.json 2> $OUT/config5.err || exit 1
