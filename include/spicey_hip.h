@@ -151,6 +151,8 @@ typedef struct SpiceyInfo {
   int64_t front_ws_bytes;   /* front workspace per instance */
   int32_t pcr_rows;         /* interpreter 2: rows of the tridiagonal top solved by one wave with parallel cyclic reduction (0 = none) */
   int32_t pcr_level;        /* first elimination-tree level of that top */
+  int32_t hybrid_entries;   /* interpreter 2, hybrid workspace: entries of L+U (those the leaves of the elimination tree own) kept in
+                               global memory because the whole L+U does not fit the LDS of one CU; 0 = everything in LDS */
 } SpiceyInfo;
 
 typedef struct SpiceyHandle SpiceyHandle;

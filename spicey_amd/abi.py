@@ -49,7 +49,7 @@ class SpiceyInfo(C.Structure):
                 ("resident_tasks", C.c_int64), ("streamed_tasks", C.c_int64), ("program_bytes", C.c_int64),
                 ("algorithmic_bytes_solve", C.c_int64), ("factor_reuse", C.c_int32), ("n_fronts", C.c_int32),
                 ("front_cut", C.c_int32), ("max_front", C.c_int32), ("front_ws_bytes", C.c_int64),
-                ("pcr_rows", C.c_int32), ("pcr_level", C.c_int32)]
+                ("pcr_rows", C.c_int32), ("pcr_level", C.c_int32), ("hybrid_entries", C.c_int32)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -176,10 +176,11 @@ struct GpuGroupExec {
   }
   // ONE lane waits until *word has reached `want` (wrap-safe signed distance).  Every wait is bounded in TIME: `limit` ticks
   // of the chip-wide 100 MHz counter (SpiceyRun::grp_timeout_ticks; the clock is looked at every 1024 polls, the first time
-  // ~0.4 ms into the wait, which starts the measurement).  At the same cadence the word is also read by an atomic
+  // ~0.15 ms into the wait, which starts the measurement).  At the same cadence the word is also read by an atomic
   // read-modify-write (+0), which is served at the memory side and cannot return a stale cached line: should the plain
-  // `sc1` poll ever fail to see a value that is there, the wait ends at the next such read and counter[8] counts it
-  // (spicey_group_stale_polls) instead of running into the deadline.  Returns false when the launch is aborting.
+  // `sc1` poll ever fail to see a value that is there, the wait ends at the next such read instead of running into the
+  // deadline, and counter[8] counts the case when a plain load issued after it still shows the old value
+  // (spicey_group_stale_polls).  Returns false when the launch is aborting.
   unsigned long long limit;
   __device__ __forceinline__ bool spin_until(unsigned int *word, unsigned int want, unsigned int kind, unsigned int what) {
     unsigned int spins = 0;
@@ -191,7 +192,11 @@ struct GpuGroupExec {
       if ((++spins & 1023u) == 0u) {
         v = __hip_atomic_fetch_add(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)(v - want) >= 0) {
-          __hip_atomic_fetch_add(counter + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // (the value may simply have arrived between the plain load above and this read: that happens about once in a
+          // thousand long waits and means nothing.  A plain load issued AFTER the read-modify-write has returned the value
+          // and STILL showing the old one does: the load path serves a stale copy — counted)
+          const unsigned int again = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((int)(again - want) < 0) __hip_atomic_fetch_add(counter + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           return true;
         }
         const unsigned long long now = (unsigned long long)wall_clock64();
@@ -461,7 +466,7 @@ struct GpuExecV2 {
   }
 };
 
-template <int K, int RMAX, int NSV, int NEL, int MAXT, int MINW>
+template <int K, int RMAX, int NSV, int NEL, int MAXT, int MINW, bool HYB = false>
 __global__ void __launch_bounds__(MAXT, MINW) spicey_tran_kernel_v2(const SpiceyProg *__restrict__ Pg, const SpiceyResident *__restrict__ Qg,
                                                                     const SpiceyRun *__restrict__ Rg) {
   const SpiceyProg &P = *Pg;
@@ -470,18 +475,29 @@ __global__ void __launch_bounds__(MAXT, MINW) spicey_tran_kernel_v2(const Spicey
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WgCtx<K> c;
   const int wg = (int)blockIdx.x;
-  const size_t nW = (size_t)P.nW * K, nU = (size_t)P.nU * K, nG = (size_t)P.nGdyn * K;
+  // LDS: the workspace (hybrid layout: without the leaf-owned entries, which live in R.hyb_G, and without the element
+  // vectors u / gd, which live in R.hyb_ug), then switch states, flags, profiling slots, tail / tridiagonal-top buffers
+  const size_t nW = HYB ? (size_t)(P.nW - P.hyb_g0 - P.hyb_g2) * K : (size_t)P.nW * K;
+  const size_t nU = HYB ? 0 : (size_t)P.nU * K, nG = HYB ? 0 : (size_t)P.nGdyn * K;
   c.W = (double *)smem;
-  c.u = c.W + nW;
-  c.gd = c.u + nU;
-  c.ison = (int32_t *)(c.gd + nG);
-  c.flags = c.ison + (size_t)P.nS * K;
 #pragma unroll
   for (int k = 0; k < K; k++) {
     const int in = wg * K + k;
     c.valid[k] = in < R.n_inst;
     c.inst[k] = in < R.n_inst ? in : R.n_inst - 1;
   }
+  if (HYB) {
+    c.G = R.hyb_G + (size_t)c.inst[0] * (size_t)P.nLU;
+    c.u = R.hyb_ug + (size_t)c.inst[0] * (size_t)(P.nU + P.nGdyn);
+    c.gd = c.u + P.nU;
+    c.ison = (int32_t *)(c.W + nW);
+  } else {
+    c.G = nullptr;
+    c.u = c.W + nW;
+    c.gd = c.u + nU;
+    c.ison = (int32_t *)(c.gd + nG);
+  }
+  c.flags = c.ison + (size_t)P.nS * K;
   GpuExecV2<ResRegs<K, RMAX, NSV, NEL>> ex;
   // profiling accumulators live in LDS behind the flags (576 B, reserved by spicey_lds_bytes)
   // (offsets from `smem`, no integer casts: the pointers must keep their LDS address space, or every access
@@ -499,7 +515,7 @@ __global__ void __launch_bounds__(MAXT, MINW) spicey_tran_kernel_v2(const Spicey
     // start stamps wait in their own slots (not in registers: nothing may stay live around the whole run)
     if (threadIdx.x == 0) { lprof[5] = (unsigned long long)clock64(); lprof[6] = (unsigned long long)wall_clock64(); }
   }
-  spicey_tran_run_v2<K, RMAX, NSV, NEL>(ex, P, Q, R, c, wg);
+  spicey_tran_run_v2<K, RMAX, NSV, NEL, HYB>(ex, P, Q, R, c, wg);
   if (R.prof) {
     __syncthreads();
     if (threadIdx.x == 0) {  // slots 5/6: whole-run shader cycles and 100 MHz wall ticks -> effective clock
@@ -511,9 +527,9 @@ __global__ void __launch_bounds__(MAXT, MINW) spicey_tran_kernel_v2(const Spicey
   }
 }
 
-template <int K, int RMAX, int NSV, int NEL, int MAXT, int MINW>
+template <int K, int RMAX, int NSV, int NEL, int MAXT, int MINW, bool HYB = false>
 hipError_t launch_v2_t(const SpiceyProg *P, const SpiceyResident *Q, const SpiceyRun *R, int grid, int threads, size_t lds, hipStream_t st) {
-  auto kern = spicey_tran_kernel_v2<K, RMAX, NSV, NEL, MAXT, MINW>;
+  auto kern = spicey_tran_kernel_v2<K, RMAX, NSV, NEL, MAXT, MINW, HYB>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -546,6 +562,8 @@ size_t spicey_front_lds_bytes(const SpiceyProg &P) {
 size_t spicey_lds_bytes(const SpiceyProg &P, int K, bool lds, int tail_n) {
   if (!lds) return 64 + spicey_front_lds_bytes(P);
   size_t b = ((size_t)P.nW + P.nU + P.nGdyn) * K * sizeof(double) + ((size_t)P.nS * K + 4) * sizeof(int32_t);
+  if (P.hybrid)  // hybrid workspace: leaf-owned entries and the element vectors are in global memory
+    b = ((size_t)P.nW - P.hyb_g0 - P.hyb_g2) * K * sizeof(double) + ((size_t)P.nS * K + 4) * sizeof(int32_t);
   b = ((b + 15) & ~size_t(15)) + SPICEY_PH_SLOTS * sizeof(unsigned long long);  // + profiling accumulators
   if (P.pcr_n > 0 && tail_n < 5) tail_n = 5;                                         // tridiagonal top: two 2 KB row buffers + its index table
   b = ((b + 15) & ~size_t(15)) + (size_t)tail_n * 64 * 16;                          // + tail task records
@@ -639,6 +657,13 @@ hipError_t spicey_launch_tran_v2(const SpiceyProg &Ph, const SpiceyResident &Qh,
   const size_t bytes = spicey_lds_bytes(Ph, K, true, Qh.tail_n);
   if (packed) {
     if (K == 1 && threads == 512) return launch_v2_t<1, 4, 6, 2, 512, 4>(P, Q, R, grid, threads, bytes, st);
+    return hipErrorInvalidValue;
+  }
+  if (Ph.hybrid) {
+    // hybrid workspace: built for 512 threads (16 slots, 8 entries, 2 elements per thread: the resident capacity of the
+    // 1024-thread geometry at half the threads; the 1024-thread build of this variant spilled 8 vector registers at its
+    // 128-register cap, which the build refuses)
+    if (K == 1 && threads == 512) return launch_v2_t<1, 16, 8, 2, 512, 2, true>(P, Q, R, grid, threads, bytes, st);
     return hipErrorInvalidValue;
   }
   if (threads <= 256) {

@@ -173,6 +173,18 @@ struct SpiceyProg {
   const int32_t *ent_ro, *ent_co;   // [nLU]
   const int32_t *pos_row, *pos_col; // [n]
 
+  // --- hybrid workspace (16-bit interpreter, circuits a little too large for the LDS of one CU): the entries that the LEAVES of
+  //     the elimination tree own (level-0 pivots: their diagonals, L and U entries — about half of L+U under nested
+  //     dissection) live in a global array G[nLU] indexed by entry id (L2-resident, read by ONE phase of the factorisation
+  //     and one of the backward sweep: two L2 round trips per solve), so do the element vectors u / gd; the LDS holds the
+  //     rest of L+U and the right-hand side / solution.  With the slot-major numbering the leaf-owned entries are the two id
+  //     ranges [0, hyb_g0) (dynamic class) and [nRestore, nRestore + hyb_g2) (never-modified class); every W index in the
+  //     16-bit records, element terminals, outputs and the tridiagonal-top table is then an LDS index
+  //     (id - hyb_g0 below nRestore, id - hyb_g0 - hyb_g2 above), except the operand fields of factor phase 0 and of the
+  //     last backward phase, which keep entry ids and are read from G.  xoff = LDS index of the right-hand side of pivot 0
+  //     (nLU without the hybrid layout).
+  int32_t hybrid, hyb_g0, hyb_g2, xoff;
+
   // --- diagnostics (SpiceyOptions.diagnostics bit 0): the structural entries of A column by column in the reference's
   //     numbering — col_ent[col_ptr[c] .. col_ptr[c + 1]) = entry id, | SPICEY_TGT_RECIP where the workspace holds the
   //     entry's reciprocal after phase B (leaf diagonals).  Fill entries (zero in A) are not listed.
@@ -266,4 +278,6 @@ struct SpiceyRun {
   unsigned long long *skip_risk;
   double *lin_vd;
   unsigned long long *lin_err;
+  // hybrid workspace (SpiceyProg::hybrid): leaf-owned entries [n_inst][nLU] and the element vectors u | gd [n_inst][nU + nGdyn]
+  double *hyb_G, *hyb_ug;
 };

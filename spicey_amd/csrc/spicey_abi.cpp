@@ -60,6 +60,7 @@ struct SpiceyHandle {
   int group_retries = 0;  // launches repeated so far (spicey_group_retries)
   // diagnostics (SpiceyOptions.diagnostics): skip-risk counters [n_inst], linearisation points [n_inst][nD], per-step
   // linearisation error [n_inst][steps + 1] of the last run (grown on demand)
+  double *d_hybG = nullptr, *d_hybUG = nullptr;  // hybrid workspace: leaf-owned entries [n_inst][nLU], u | gd [n_inst][nU + nGdyn]
   unsigned long long *d_skip = nullptr, *d_linerr = nullptr;
   double *d_linvd = nullptr;
   size_t linerr_cap = 0;
@@ -203,7 +204,7 @@ extern "C" void spicey_destroy(SpiceyHandle *h) {
     g.group_handles--;
   }
   void *ptrs[] = {h->d_res, h->d_blob, h->d_R, h->d_C, h->d_L, h->d_Sron, h->d_Sroff, h->d_Svon, h->d_Svoff, h->d_Dis, h->d_Dn, h->d_Cv,
-                  h->d_Li, h->d_Dv, h->d_Son, h->d_Cv0, h->d_Li0, h->d_Dv0, h->d_Son0, h->d_Cv_s, h->d_Li_s, h->d_Dv_s, h->d_Son_s, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_Pstruct, h->d_Qstruct, h->d_Rstruct, h->d_gsync, h->d_gflags, h->d_front_ws, h->d_fs, h->d_front_flags, h->d_status, h->d_solves, h->d_prof, h->d_skip, h->d_linerr, h->d_linvd};
+                  h->d_Li, h->d_Dv, h->d_Son, h->d_Cv0, h->d_Li0, h->d_Dv0, h->d_Son0, h->d_Cv_s, h->d_Li_s, h->d_Dv_s, h->d_Son_s, h->d_gstat, h->d_statv, h->d_rcoef, h->d_gW, h->d_dpar, h->d_Pstruct, h->d_Qstruct, h->d_Rstruct, h->d_gsync, h->d_gflags, h->d_front_ws, h->d_fs, h->d_front_flags, h->d_status, h->d_solves, h->d_prof, h->d_skip, h->d_linerr, h->d_linvd, h->d_hybG, h->d_hybUG};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -302,6 +303,22 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
     if (!want_lds || spicey_lds_bytes(P, 1, true) > SPICEY_LDS_MAX) K = (h->n_inst >= 4 * ncu && !diag) ? 4 : (h->n_inst >= 2 * ncu ? 2 : 1);
   }
   if (K > h->n_inst) K = 1;
+  // Hybrid workspace (program.h, SpiceyProg::hybrid): a circuit whose L+U no longer fits the LDS of one CU but whose upper
+  // elimination tree does keeps the 16-bit register-resident interpreter — the entries the LEAVES own (half of L+U under
+  // nested dissection) and the element vectors move to global memory, read by one factor phase and one backward phase.
+  // Without it such a circuit falls to the 32-bit task lists on a global workspace (diode_chain(2600): 56 us per step on 16
+  // cooperating workgroups against ~16 for the 2000-node chain that still fits).  One instance per workgroup, 512 threads.
+  if (want_lds && (h->opt.inst_per_wg == 0 || h->opt.inst_per_wg == 1) && h->opt.interpreter != 1 && h->opt.geometry != 2 && P.has16 && P.nFronts == 0 &&
+      (h->opt.threads == 0 || h->opt.threads == 512) && h->opt.wgs_per_inst <= 1 && !diag && !getenv("SPICEY_NO_HYBRID") &&
+      spicey_lds_bytes(P, 1, true, 5) > SPICEY_LDS_MAX) {
+    HostProgram hyb;
+    std::string err2;
+    if (spicey_build_program(desc, hyb, err2, true, 0, pcr_top, true) == SPICEY_OK && hyb.hdr.hybrid && !hyb.ph_cnt.empty() && hyb.ph_cnt[0] > 64 &&
+        spicey_lds_bytes(hyb.hdr, 1, true, 5) <= SPICEY_LDS_MAX) {
+      h->hp = std::move(hyb);
+      K = 1;
+    }
+  }
   h->lds = want_lds && spicey_lds_bytes(P, K, true) <= SPICEY_LDS_MAX;
   if (!h->lds && want_lds && K > 1 && spicey_lds_bytes(P, 1, true) <= SPICEY_LDS_MAX) {
     K = 1;  // one instance fits LDS where K interleaved ones do not: LDS wins
@@ -314,6 +331,10 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   if (h->opt.interpreter == 2 && !v2_ok) { h->err = "interpreter 2 needs the LDS workspace, < 65536 workspace entries and inst_per_wg = 1"; return fail(SPICEY_ERR_BAD_DESC); }
   h->interp = (h->opt.interpreter == 1 || !v2_ok) ? 1 : 2;
   h->T = h->opt.threads > 0 ? h->opt.threads : pick_threads(h->hp, h->interp == 2, K);
+  if (P.hybrid) {
+    if (h->interp != 2) { h->err = "internal: hybrid layout without the 16-bit interpreter"; return fail(SPICEY_ERR_BAD_DESC); }
+    h->T = 512;  // (the geometry the hybrid kernel is built for: kernels.hip, spicey_launch_tran_v2)
+  }
   if (P.nFronts > 0 && h->T > 512) {  // kernels with the dense-front code are built for <= 512 threads (256 VGPRs)
     if (h->opt.threads > 512) { h->err = "front_cut needs threads <= 512"; return fail(SPICEY_ERR_BAD_DESC); }
     h->T = 512;
@@ -330,7 +351,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
                           P.nRestore <= spicey_v2_nsv(512, true) * 512 && (h->opt.threads == 0 || h->opt.threads == 512);
     if (h->opt.geometry == 2 && !packable) { h->err = "geometry 2 needs inst_per_wg = 1, <= 80 KB of LDS per instance and <= 1024 unknowns"; return fail(SPICEY_ERR_BAD_DESC); }
     if (h->opt.geometry < 0 || h->opt.geometry > 2) { h->err = "geometry must be 0, 1 or 2"; return fail(SPICEY_ERR_BAD_DESC); }
-    h->packed = packable && !diag && (h->opt.geometry == 2 || (h->opt.geometry == 0 && h->n_inst >= 2 * ncu && h->opt.threads == 0));
+    h->packed = packable && !diag && !P.hybrid && (h->opt.geometry == 2 || (h->opt.geometry == 0 && h->n_inst >= 2 * ncu && h->opt.threads == 0));
     if (h->packed) { h->T = 512; h->grid = (h->n_inst + K - 1) / K; }
     // tail levels go to LDS: as many as fit beside the workspace (1 KB each), at most 24; the packed geometry
     // must leave room for a second workgroup on the CU
@@ -455,6 +476,10 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   if (h->opt.profile)
     // (+ per-front event times behind the per-workgroup section timers)
     if ((rc = upload(h, &h->d_prof, noull, (size_t)h->grid * h->G * 72 + (size_t)h->grid * 4 * (size_t)P.nFronts)) != SPICEY_OK) return fail(rc);
+  if (P.hybrid) {
+    if ((rc = upload(h, &h->d_hybG, nodbl, ni * (size_t)P.nLU)) != SPICEY_OK) return fail(rc);
+    if ((rc = upload(h, &h->d_hybUG, nodbl, ni * (size_t)(P.nU + P.nGdyn))) != SPICEY_OK) return fail(rc);
+  }
   if (h->opt.diagnostics & 1)
     if ((rc = upload(h, &h->d_skip, noull, ni)) != SPICEY_OK) return fail(rc);
   if ((h->opt.diagnostics & 2) && P.nD > 0)
@@ -496,6 +521,7 @@ extern "C" int32_t spicey_get_info(SpiceyHandle *h, SpiceyInfo *info) {
   info->front_ws_bytes = h->hp.hdr.front_ws * (int64_t)sizeof(double);
   info->pcr_rows = (h->interp == 2 && h->K == 1) ? h->hp.hdr.pcr_n : 0;
   info->pcr_level = info->pcr_rows ? h->hp.hdr.pcr_level : 0;
+  info->hybrid_entries = h->hp.hdr.hybrid ? h->hp.hdr.hyb_g0 + h->hp.hdr.hyb_g2 : 0;
   return SPICEY_OK;
 }
 
@@ -571,6 +597,7 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
     R.lin_err = h->d_linerr;
     R.lin_vd = h->d_linvd;  // (null without diodes: the error stays 0)
   }
+  R.hyb_G = h->d_hybG; R.hyb_ug = h->d_hybUG;
   R.front_ticks = (h->d_prof && h->hp.hdr.nFronts > 0) ? h->d_prof + (size_t)h->grid * h->G * 72 : nullptr;
   R.wgs_per_group = h->G;
   R.grp_sync = h->d_gsync;

@@ -330,7 +330,7 @@ int64_t spicey_algorithmic_bytes(const SpiceyDesc *d, int32_t nnzA, int32_t nnzL
          16 * ((int64_t)d->nC + d->nL + d->nD) + 8 * ((int64_t)d->n_nodes + etot);
 }
 
-static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool slot_major, int front_cut, bool pcr_top);
+static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool slot_major, int front_cut, bool pcr_top, bool hybrid = false);
 
 
 // LDS cycles the operand reads of the compact records cost per solve (every half-wave group and operand role: the
@@ -370,8 +370,9 @@ void spicey_bank_cost(const HostProgram &hp, int64_t *cycles, int64_t *ideal) {
 // order.  For programs that run from LDS (16-bit records) both are compiled and the one whose operand reads cost fewer
 // LDS cycles is kept (chains: 2.65 -> 1.88 conflict factor; small meshes are sometimes better off in CSR order).
 // Circuits on the global-workspace path keep the CSR order: LDS banks do not matter there.
-int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware, int front_cut, bool pcr_top) {
+int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware, int front_cut, bool pcr_top, bool hybrid) {
   hp = HostProgram();
+  if (hybrid) return build_program_impl(d, hp, err, true, 0, pcr_top, true);  // (the leaf-owned id ranges need the slot-major numbering)
   int32_t rc = build_program_impl(d, hp, err, false, front_cut, pcr_top);
   if (rc != SPICEY_OK || hp.structurally_singular || !hp.hdr.has16 || !bank_aware) return rc;
   HostProgram alt;
@@ -385,7 +386,7 @@ int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &
   return rc;
 }
 
-static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, const bool slot_major, int front_cut, const bool pcr_top) {
+static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::string &err, const bool slot_major, int front_cut, const bool pcr_top, const bool hybrid) {
   if (!d) { err = "null descriptor"; return SPICEY_ERR_BAD_DESC; }
   if (d->abi_version != SPICEY_ABI_VERSION) { err = "abi_version mismatch"; return SPICEY_ERR_BAD_DESC; }
   const int nN = d->n_nodes, nR = d->nR, nC = d->nC, nL = d->nL, nV = d->nV, nS = d->nS, nD = d->nD;
@@ -1375,6 +1376,110 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     }
   }
 
+  // ---- 6. hybrid workspace layout (program.h: SpiceyProg::hybrid) ---------------------------------------------------------
+  hp.hdr.hybrid = 0; hp.hdr.hyb_g0 = 0; hp.hdr.hyb_g2 = 0; hp.hdr.xoff = nLU;
+  if (hybrid && slot_major && hp.hdr.has16 && Lc == 0 && nLevels >= 3 && !hp.structurally_singular) {
+    // the leaf-owned entries: ids [0, g0) of the dynamic class and [nRestore, nRestore + g2) of the never-modified class
+    // (inside a class the slot-major numbering sorts by the level of the owning pivot; a leaf-owned entry is never an
+    // update target: targets lie among the ancestors of the eliminated pivot)
+    const int nRest = hp.hdr.nRestore;
+    auto leaf_owned = [&](int e) { return hp.level[std::min(E.row_of_id[e], E.col_of_id[e])] == 0; };
+    int g0 = 0, g2 = 0;
+    while (g0 < nRest && leaf_owned(g0)) g0++;
+    while (nRest + g2 < nLU && leaf_owned(nRest + g2)) g2++;
+    bool ok = true;
+    for (int e = 0; e < nLU && ok; e++) ok = leaf_owned(e) == (e < g0 || (e >= nRest && e < nRest + g2));
+    if (ok && g0 + g2 > 0) {
+      const uint32_t G0 = (uint32_t)g0, G2 = (uint32_t)g2, NR = (uint32_t)nRest;
+      auto is_glob = [&](uint32_t w) { return w < G0 || (w >= NR && w < NR + G2); };
+      auto lds = [&](uint32_t w) -> uint32_t { return w < NR ? w - G0 : w - G0 - G2; };  // (w must not be a leaf-owned entry)
+      bool bad = false;
+      auto L16 = [&](uint32_t w) -> uint32_t { if (is_glob(w)) bad = true; return lds(w); };
+      auto G16 = [&](uint32_t w) -> uint32_t { if (!is_glob(w)) bad = true; return w; };
+      // 16-bit records of one phase, `count` of them from 16-byte unit `first` of `arr`; opg: the pivot operands are leaf-owned
+      auto fix_generic = [&](std::vector<uint32_t> &arr, size_t first, size_t count, bool ktask, bool opg) {
+        for (size_t i = 0; i < count; i++) {
+          uint32_t *r = &arr[(first + i) * 4];
+          const uint32_t meta = r[0] >> 16, cnt = meta & 0xffu;
+          if (!(meta & (SPICEY_R16_VALID << 8))) continue;
+          const uint32_t tgt_old = r[0] & 0xffffu;
+          const bool rhs_task = tgt_old >= (uint32_t)nLU;
+          r[0] = L16(tgt_old) | (meta << 16);
+          if (ktask) {
+            const uint32_t dg = r[1] & 0xffffu;
+            const uint32_t dnew = opg ? G16(dg) : L16(dg);
+            if (cnt <= 2) {
+              uint32_t u0 = r[1] >> 16, x0 = r[2] & 0xffffu, u1 = r[2] >> 16, x1 = r[3] & 0xffffu;
+              if (cnt >= 1) { u0 = opg ? G16(u0) : L16(u0); x0 = L16(x0); }
+              if (cnt == 2) { u1 = opg ? G16(u1) : L16(u1); x1 = L16(x1); }
+              r[1] = dnew | (u0 << 16); r[2] = x0 | (u1 << 16); r[3] = x1;
+            } else {
+              r[1] = dnew;
+              for (uint32_t j = 0; j < cnt; j++) {
+                uint16_t &u = hp.ovf16[r[3] + 2 * j], &x = hp.ovf16[r[3] + 2 * j + 1];
+                u = (uint16_t)(opg ? G16(u) : L16(u)); x = (uint16_t)L16(x);
+              }
+            }
+          } else {
+            // third operand of a right-hand-side task: y_k, an LDS index in every phase
+            auto third = [&](uint32_t u) { return (opg && !rhs_task) ? G16(u) : L16(u); };
+            if (cnt <= 2) {
+              uint32_t l0 = r[1] & 0xffffu, d0 = r[1] >> 16, u0 = r[2] & 0xffffu, l1 = r[2] >> 16, d1 = r[3] & 0xffffu, u1 = r[3] >> 16;
+              if (cnt >= 1) { l0 = opg ? G16(l0) : L16(l0); d0 = opg ? G16(d0) : L16(d0); u0 = third(u0); }
+              if (cnt == 2) { l1 = opg ? G16(l1) : L16(l1); d1 = opg ? G16(d1) : L16(d1); u1 = third(u1); }
+              r[1] = l0 | (d0 << 16); r[2] = u0 | (l1 << 16); r[3] = d1 | (u1 << 16);
+            } else {
+              for (uint32_t j = 0; j < cnt; j++) {
+                uint16_t *t = &hp.ovf16[r[3] + 3 * j];
+                t[0] = (uint16_t)(opg ? G16(t[0]) : L16(t[0])); t[1] = (uint16_t)(opg ? G16(t[1]) : L16(t[1])); t[2] = (uint16_t)third(t[2]);
+              }
+            }
+          }
+        }
+      };
+      // (an overflow list belongs to ONE record of rec16 and, when the phase has a row-record encoding, to its twin in fus16,
+      // which was emitted with its own copy: emit_u appends to ovf16 per call — so every list is fixed exactly once)
+      for (int p = 0; p < 2 * nLevels; p++) {
+        const bool ktask = p >= nLevels;
+        const int lvl = ktask ? 2 * nLevels - 1 - p : p;
+        fix_generic(hp.rec16, hp.ph_first[p], hp.ph_cnt[p], ktask, lvl == 0);
+        if (!ktask && hp.fus_pairs[p] > 0) {
+          fix_generic(hp.fus16, hp.fus_first[p], hp.fus_gen[p], false, lvl == 0);
+          for (uint32_t i = 0; i < hp.fus_pairs[p]; i++) {
+            uint32_t *w = &hp.fus16[((size_t)hp.fus_first[p] + hp.fus_gen[p]) * 4 + (size_t)i * 8];
+            uint16_t h[16];
+            for (int q = 0; q < 8; q++) { h[2 * q] = (uint16_t)(w[q] & 0xffffu); h[2 * q + 1] = (uint16_t)(w[q] >> 16); }
+            const uint32_t meta = h[1], np = meta & 3u;
+            h[0] = (uint16_t)L16(h[0]); h[2] = (uint16_t)L16(h[2]);
+            for (uint32_t i2 = 0; i2 < np; i2++) {
+              uint16_t *q = h + 3 + 6 * i2;
+              const bool opg = lvl == 0;
+              q[0] = (uint16_t)(opg ? G16(q[0]) : L16(q[0])); q[1] = (uint16_t)(opg ? G16(q[1]) : L16(q[1])); q[2] = (uint16_t)(opg ? G16(q[2]) : L16(q[2]));
+              q[3] = (uint16_t)L16(q[3]);
+              if ((meta >> (4 + i2)) & 1u) { q[4] = (uint16_t)(opg ? G16(q[4]) : L16(q[4])); q[5] = (uint16_t)L16(q[5]); }
+            }
+            for (int q = 0; q < 8; q++) w[q] = (uint32_t)h[2 * q] | ((uint32_t)h[2 * q + 1] << 16);
+          }
+        }
+      }
+      for (auto &v : hp.pcr_tab) if (v != 0xFFFFu) v = (uint16_t)L16(v);
+      auto fix_i32 = [&](std::vector<int32_t> &a) { for (auto &v : a) if (v >= 0) v = (int32_t)L16((uint32_t)v); };
+      fix_i32(hp.R_a); fix_i32(hp.R_b); fix_i32(hp.C_a); fix_i32(hp.C_b); fix_i32(hp.L_a); fix_i32(hp.L_b); fix_i32(hp.S_a); fix_i32(hp.S_b);
+      fix_i32(hp.S_cp); fix_i32(hp.S_cn); fix_i32(hp.D_a); fix_i32(hp.D_b); fix_i32(hp.V_x); fix_i32(hp.out_x);
+      auto fix_ab = [&](std::vector<uint32_t> &a) {
+        for (auto &v : a) {
+          uint32_t lo = v & 0xffffu, hi = v >> 16;
+          if (lo != 0xFFFFu) lo = L16(lo);
+          if (hi != 0xFFFFu) hi = L16(hi);
+          v = lo | (hi << 16);
+        }
+      };
+      fix_ab(hp.R_ab); fix_ab(hp.C_ab); fix_ab(hp.L_ab); fix_ab(hp.D_ab);
+      if (bad) { err = "internal: hybrid layout met an index on the wrong side"; return SPICEY_ERR_BAD_DESC; }
+      hp.hdr.hybrid = 1; hp.hdr.hyb_g0 = g0; hp.hdr.hyb_g2 = g2; hp.hdr.xoff = nLU - g0 - g2;
+    }
+  }
+
   hp.pack();
   return SPICEY_OK;
 }
@@ -1483,8 +1588,10 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
     // tail: longest run of <= 64-task phases around the factor -> backward turn (phase nLevels-1 | nLevels)
     const int nL = hp.hdr.nLevels;
     int a = nL, b = nL;  // [a, b)
-    while (a > 0 && hp.ph_cnt[a - 1] <= 64 && b - (a - 1) <= max_tail) a--;
-    while (b < nPh && hp.ph_cnt[b] <= 64 && (b + 1) - a <= max_tail) b++;
+    // (hybrid workspace: the two phases of the leaves read their operands from the global array — they stay ordinary phases)
+    const int a_min = hp.hdr.hybrid ? 1 : 0, b_max = hp.hdr.hybrid ? nPh - 1 : nPh;
+    while (a > a_min && hp.ph_cnt[a - 1] <= 64 && b - (a - 1) <= max_tail) a--;
+    while (b < b_max && hp.ph_cnt[b] <= 64 && (b + 1) - a <= max_tail) b++;
     while (a < b && hp.ph_cnt[a] == 0) a++;  // skip empty leading phases (the top factor level has no tasks)
     if (b - a >= 3) { out.tail_first = a; out.tail_n = b - a; }
   }

@@ -56,7 +56,9 @@ struct HostProgram {
 // front_cut: elimination-tree level from which pivots are factored as dense fronts (fronts_exec.h); 0 = no fronts,
 // -1 = automatic (large nonlinear circuits only).
 // pcr_top: let the 16-bit records stop below a tridiagonal top that one wave solves by parallel cyclic reduction.
-int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware = true, int front_cut = 0, bool pcr_top = true);
+// hybrid: lay the program out for the hybrid workspace (program.h: leaf-owned entries in global memory) — slot-major numbering
+// only, no fronts; hp.hdr.hybrid stays 0 when the circuit has no 16-bit records or fewer than 3 levels.
+int32_t spicey_build_program(const SpiceyDesc *d, HostProgram &hp, std::string &err, bool bank_aware = true, int front_cut = 0, bool pcr_top = true, bool hybrid = false);
 
 // Front schedule for G cooperating workgroups (proportional mapping of the front tree: a subtree's workgroup range is
 // split among its children by work; a front runs on the first workgroup of its range once its children are done).

@@ -100,6 +100,7 @@ static __device__ __forceinline__ double spicey_wave_max(double x) {
 template <int K>
 struct WgCtx {
   double *W;     // [nW][K]   L+U entries, then rhs / x'
+  double *G;     // hybrid workspace (SpiceyProg::hybrid): leaf-owned entries in global memory, [nLU][K] by entry id; else null
   double *u;     // [nU][K]   vPrev | iPrev | V(t) | diode ieq
   double *gd;    // [nGdyn][K] switch conductances | diode gd
   int32_t *ison; // [nS][K]
@@ -165,7 +166,7 @@ SPICEY_HD double spicey_switch_g(int on, double ron, double roff) {  // simulate
 // indicator of that situation (exact for the first pivot; fills and updated entries are not looked at).  One thread per
 // column, read-only, no influence on the solve.  `weight` = solves the count stands for (a linear circuit's matrix is
 // looked at once, at step 0, for all its steps).
-template <int K>
+template <int K, bool HYB = false>
 SPICEY_HD void spicey_skip_risk(const SpiceyProg &P, const SpiceyRun &R, const WgCtx<K> &c, int tid, int T, unsigned long long weight) {
   SPICEY_NOUNROLL
   for (int col = tid; col < P.n; col += T) {
@@ -176,7 +177,15 @@ SPICEY_HD void spicey_skip_risk(const SpiceyProg &P, const SpiceyRun &R, const W
       bool any = false;
       for (uint32_t j = j0; j < j1; j++) {
         const uint32_t e = P.col_ent[j];
-        double v = fabs(c.W[(size_t)SPICEY_IDX(e) * K + k]);
+        const uint32_t id = SPICEY_IDX(e);
+        double v;
+        if (HYB) {  // hybrid workspace: leaf-owned entries in the global array, the others at their LDS index
+          const uint32_t g0 = (uint32_t)P.hyb_g0, nr = (uint32_t)P.nRestore, g2 = (uint32_t)P.hyb_g2;
+          if (id < g0 || (id >= nr && id < nr + g2)) v = fabs(c.G[(size_t)id * K + k]);
+          else v = fabs(c.W[(size_t)(id - g0 - (id >= nr ? g2 : 0u)) * K + k]);
+        } else {
+          v = fabs(c.W[(size_t)id * K + k]);
+        }
         if (e & SPICEY_TGT_RECIP) v = 1.0 / v;
         if (v != 0.0) { any = true; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
       }
@@ -604,15 +613,20 @@ struct ResRegs {
 // One task.  For the common inline case (<= 2 products) ALL operands are fetched up front — unused index fields
 // are 0, a valid address — and the unused products are masked by selects: one LDS round trip per task instead of
 // one per product (the dependent ds_read -> wait -> fma chains dominated the small phases).
-template <int K, bool KTASK>
+// OPG (hybrid workspace, SpiceyProg::hybrid): the phase eliminates / back-substitutes the LEAVES of the elimination tree —
+// the pivot's own entries (L, reciprocal diagonal, U) are read from the global array c.G by entry id, every target and
+// every right-hand-side / solution operand from LDS as always (`xoff` = first LDS index of the right-hand side: the third
+// operand of a right-hand-side task is y_k, not an entry).
+template <int K, bool KTASK, bool OPG = false>
 SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
-                                 uint32_t keep_from = 0u) {
+                                 uint32_t keep_from = 0u, uint32_t xoff = 0u) {
   const uint32_t meta = w0 >> 16;
   if (!(meta & (SPICEY_R16_VALID << 8))) return;
   const uint32_t tgt = w0 & 0xffffu, cnt = meta & 0xffu;
   // a reused factorisation (linear circuit, step > 0) runs only the right-hand-side column of the factor tasks:
-  // keep_from = nLU then, 0 otherwise
+  // keep_from = first right-hand-side index then, 0 otherwise
   if (!KTASK && tgt < keep_from) return;
+  const double *E = OPG ? c.G : c.W;  // where the pivot's own entries are
   double acc[K];
   if (KTASK) {
     const uint32_t d = w1 & 0xffffu;
@@ -622,11 +636,11 @@ SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_
       double a0[K], b0[K], a1[K], b1[K], dv[K];
       for (int k = 0; k < K; k++) {
         acc[k] = c.W[(size_t)tgt * K + k];
-        a0[k] = c.W[(size_t)u0 * K + k]; b0[k] = c.W[(size_t)x0 * K + k];
-        dv[k] = c.W[(size_t)d * K + k];
+        a0[k] = E[(size_t)u0 * K + k]; b0[k] = c.W[(size_t)x0 * K + k];
+        dv[k] = E[(size_t)d * K + k];
       }
       if (two)
-        for (int k = 0; k < K; k++) { a1[k] = c.W[(size_t)u1 * K + k]; b1[k] = c.W[(size_t)x1 * K + k]; }
+        for (int k = 0; k < K; k++) { a1[k] = E[(size_t)u1 * K + k]; b1[k] = c.W[(size_t)x1 * K + k]; }
       for (int k = 0; k < K; k++) {  // explicit fma: the same rounding in every interpreter and geometry
         const double s0 = fma(-a0[k], b0[k], acc[k]);
         acc[k] = cnt >= 1 ? s0 : acc[k];
@@ -641,22 +655,29 @@ SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_
       const uint16_t *o = ovf + w3;
       for (uint32_t j = 0; j < cnt; j++) {
         const uint32_t u = o[2 * j], x = o[2 * j + 1];
-        for (int k = 0; k < K; k++) acc[k] = fma(-c.W[(size_t)u * K + k], c.W[(size_t)x * K + k], acc[k]);
+        for (int k = 0; k < K; k++) acc[k] = fma(-E[(size_t)u * K + k], c.W[(size_t)x * K + k], acc[k]);
       }
-      for (int k = 0; k < K; k++) acc[k] *= c.W[(size_t)d * K + k];
+      for (int k = 0; k < K; k++) acc[k] *= E[(size_t)d * K + k];
     }
     for (int k = 0; k < K; k++) c.W[(size_t)tgt * K + k] = acc[k];
   } else {
+    // (hybrid: the third operand is an entry of the pivot's U row — global — for a matrix target, y_k — LDS — for a
+    // right-hand-side target)
+    const bool third_lds = !OPG || tgt >= xoff;
     if (cnt <= 2) {
       const uint32_t l0 = w1 & 0xffffu, d0 = w1 >> 16, u0 = w2 & 0xffffu, l1 = w2 >> 16, d1 = w3 & 0xffffu, u1 = w3 >> 16;
       const bool two = SPICEY_WAVE_ANY(cnt == 2);
       double p0[K], q0[K], r0[K], p1[K], q1[K], r1[K];
       for (int k = 0; k < K; k++) {
         acc[k] = c.W[(size_t)tgt * K + k];
-        p0[k] = c.W[(size_t)l0 * K + k]; q0[k] = c.W[(size_t)d0 * K + k]; r0[k] = c.W[(size_t)u0 * K + k];
+        p0[k] = E[(size_t)l0 * K + k]; q0[k] = E[(size_t)d0 * K + k];
+        r0[k] = (!OPG || third_lds) ? c.W[(size_t)u0 * K + k] : c.G[(size_t)u0 * K + k];
       }
       if (two)
-        for (int k = 0; k < K; k++) { p1[k] = c.W[(size_t)l1 * K + k]; q1[k] = c.W[(size_t)d1 * K + k]; r1[k] = c.W[(size_t)u1 * K + k]; }
+        for (int k = 0; k < K; k++) {
+          p1[k] = E[(size_t)l1 * K + k]; q1[k] = E[(size_t)d1 * K + k];
+          r1[k] = (!OPG || third_lds) ? c.W[(size_t)u1 * K + k] : c.G[(size_t)u1 * K + k];
+        }
       for (int k = 0; k < K; k++) {
         const double s0 = fma(-(p0[k] * q0[k]), r0[k], acc[k]);
         acc[k] = cnt >= 1 ? s0 : acc[k];
@@ -670,7 +691,10 @@ SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_
       const uint16_t *o = ovf + w3;
       for (uint32_t j = 0; j < cnt; j++) {
         const uint32_t l = o[3 * j], d = o[3 * j + 1], u = o[3 * j + 2];
-        for (int k = 0; k < K; k++) acc[k] = fma(-(c.W[(size_t)l * K + k] * c.W[(size_t)d * K + k]), c.W[(size_t)u * K + k], acc[k]);
+        for (int k = 0; k < K; k++) {
+          const double uv = (!OPG || third_lds) ? c.W[(size_t)u * K + k] : c.G[(size_t)u * K + k];
+          acc[k] = fma(-(E[(size_t)l * K + k] * E[(size_t)d * K + k]), uv, acc[k]);
+        }
       }
     }
     if (meta & (SPICEY_R16_RECIP << 8)) {
@@ -686,8 +710,9 @@ SPICEY_HD void spicey_exec_rec16(const WgCtx<K> &c, const uint16_t *ovf, uint32_
 // One ROW record of a factor phase (program.h: fus16): the targets a_ii, y_i and the (at most two) fills of row i from its
 // (at most two) pivots of this level, sharing the multipliers -(L_ik d_k).  The products and their order are those of the
 // generic tasks it stands for.  rhs_only: a reused factorisation updates y_i alone.
-template <int K>
+template <int K, bool OPG = false>
 SPICEY_HD void spicey_exec_row16(const WgCtx<K> &c, const uint32_t *w, bool rhs_only) {
+  const double *E = OPG ? c.G : c.W;  // (hybrid workspace: the pivots' own entries L_ik, d_k, U_ki, U_k,o come from the global array)
   const uint32_t meta = w[0] >> 16;
   if (!(meta & (SPICEY_R16_VALID << 8))) return;
   const uint32_t iaa = w[0] & 0xffffu, iy = w[1] & 0xffffu;
@@ -697,9 +722,9 @@ SPICEY_HD void spicey_exec_row16(const WgCtx<K> &c, const uint32_t *w, bool rhs_
   for (int k = 0; k < K; k++) {
     // every operand in one LDS round trip (an unused second pivot / fill: index 0, a valid address; results masked)
     double aii = c.W[(size_t)iaa * K + k], yi = c.W[(size_t)iy * K + k];
-    const double vl0 = c.W[(size_t)l0 * K + k], vd0 = c.W[(size_t)d0 * K + k], vy0 = c.W[(size_t)y0 * K + k], vu0 = c.W[(size_t)u0 * K + k];
-    const double vl1 = c.W[(size_t)l1 * K + k], vd1 = c.W[(size_t)d1 * K + k], vy1 = c.W[(size_t)y1 * K + k], vu1 = c.W[(size_t)u1 * K + k];
-    const double vf0 = c.W[(size_t)f0 * K + k], vt0 = c.W[(size_t)t0 * K + k], vf1 = c.W[(size_t)f1 * K + k], vt1 = c.W[(size_t)t1 * K + k];
+    const double vl0 = E[(size_t)l0 * K + k], vd0 = E[(size_t)d0 * K + k], vy0 = c.W[(size_t)y0 * K + k], vu0 = E[(size_t)u0 * K + k];
+    const double vl1 = E[(size_t)l1 * K + k], vd1 = E[(size_t)d1 * K + k], vy1 = c.W[(size_t)y1 * K + k], vu1 = E[(size_t)u1 * K + k];
+    const double vf0 = E[(size_t)f0 * K + k], vt0 = c.W[(size_t)t0 * K + k], vf1 = E[(size_t)f1 * K + k], vt1 = c.W[(size_t)t1 * K + k];
     const double m0 = -(vl0 * vd0), m1 = -(vl1 * vd1);
     yi = fma(m0, vy0, yi);
     aii = fma(m0, vu0, aii);
@@ -719,10 +744,11 @@ SPICEY_HD void spicey_exec_row16(const WgCtx<K> &c, const uint32_t *w, bool rhs_
   }
 }
 
-template <int K, int RMAX, int NSV, int NEL, bool KTASK>
+template <int K, int RMAX, int NSV, int NEL, bool KTASK, bool OPG = false>
 SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, const WgCtx<K> &c, ResRegs<K, RMAX, NSV, NEL> &rr, int tid,
                                int T, int p, bool streamed, bool reuse = false) {
-  const uint32_t keep_from = (!KTASK && reuse) ? (uint32_t)P.nLU : 0u;
+  const uint32_t xoff = (uint32_t)P.xoff;  // first LDS index of the right-hand side (= nLU without the hybrid layout)
+  const uint32_t keep_from = (!KTASK && reuse) ? xoff : 0u;
   if (RMAX <= 8) {
     // few slots: a static compare chain (scalar compares on the wave-uniform phase bytes).  Measured faster than
     // both indexed register access and a binary decision tree on a slot cursor (11.8 vs 16.0 / 15.2 us per step).
@@ -737,9 +763,9 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
         if (!KTASK && s + 1 < RMAX && SPICEY_UNIFORM((int)((rr.phv[(s + 1) >> 2] >> (((s + 1) & 3) * 8)) & 0xffu)) == 0xFE) {  // a chunk of row records: this slot + its continuation
           uint32_t w[8] = {w0, w1, w2, w3, rr.w0[s + 1 < RMAX ? s + 1 : s], rr.w1[s + 1 < RMAX ? s + 1 : s], rr.w2[s + 1 < RMAX ? s + 1 : s], rr.w3[s + 1 < RMAX ? s + 1 : s]};
           SPICEY_OPAQUE(w[4]); SPICEY_OPAQUE(w[5]); SPICEY_OPAQUE(w[6]); SPICEY_OPAQUE(w[7]);
-          spicey_exec_row16<K>(c, w, reuse);
+          spicey_exec_row16<K, OPG>(c, w, reuse);
         } else {
-          spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3, keep_from);
+          spicey_exec_rec16<K, KTASK, OPG>(c, P.ovf16, w0, w1, w2, w3, keep_from, xoff);
         }
       }
     }
@@ -756,10 +782,10 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
       if (!KTASK && q + 1 < RMAX && SPICEY_UNIFORM((int)((rr.phv[(q + 1) >> 2] >> (((q + 1) & 3) * 8)) & 0xffu)) == 0xFE) {  // a chunk of row records: this slot + its continuation
         uint32_t w[8] = {w0, w1, w2, w3, rr.w0[q + 1], rr.w1[q + 1], rr.w2[q + 1], rr.w3[q + 1]};
         SPICEY_OPAQUE(w[4]); SPICEY_OPAQUE(w[5]); SPICEY_OPAQUE(w[6]); SPICEY_OPAQUE(w[7]);
-        spicey_exec_row16<K>(c, w, reuse);
+        spicey_exec_row16<K, OPG>(c, w, reuse);
         q += 2;
       } else {
-        spicey_exec_rec16<K, KTASK>(c, P.ovf16, w0, w1, w2, w3, keep_from);
+        spicey_exec_rec16<K, KTASK, OPG>(c, P.ovf16, w0, w1, w2, w3, keep_from, xoff);
         q++;
       }
     }
@@ -780,7 +806,7 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
     for (uint32_t j = (uint32_t)tid; j < npair; j += (uint32_t)T) {
       uint32_t w[8];
       for (int i = 0; i < 8; i++) w[i] = pb[(size_t)j * 8 + i];
-      spicey_exec_row16<K>(c, w, reuse);
+      spicey_exec_row16<K, OPG>(c, w, reuse);
     }
     base = P.fus16 + (size_t)d_rfirst * 4;
     sc = reuse ? d_rrhs : d_rcnt;
@@ -798,7 +824,7 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
         const bool more = jn < sc;
         const uint32_t *rn = base + (size_t)(more ? jn : j) * 4;
         const uint32_t n0 = rn[0], n1 = rn[1], n2 = rn[2], n3 = rn[3];
-        spicey_exec_rec16<K, KTASK>(c, P.ovf16, c0, c1, c2, c3, keep_from);
+        spicey_exec_rec16<K, KTASK, OPG>(c, P.ovf16, c0, c1, c2, c3, keep_from, xoff);
         if (!more) break;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         j = jn;
@@ -812,12 +838,24 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
 // resident capacity (entries >= NSV*T, rows / elements >= T) take the streamed remainder loops.
 // Difference to v1: u[c] holds the capacitor companion CURRENT gc*vPrev (so the right-hand side is a
 // pure +-1 gather, stampCurrentReal.ts:12-13) and the exact vPrev lives in a register.
-template <int K, int RMAX, int NSV, int NEL>
+// HYB: the hybrid workspace layout (program.h, SpiceyProg::hybrid) — entry ids below hyb_g0 and in [nRestore, nRestore + hyb_g2)
+// are leaf-owned and live in the global array c.G, all others in LDS at id - hyb_g0 (- hyb_g2 above nRestore); the
+// right-hand side starts at LDS index P.xoff; c.u / c.gd point to global memory.
+template <int K, int RMAX, int NSV, int NEL, bool HYB = false>
 struct TranPhases2 {
   const SpiceyProg &P;
   const SpiceyRun &R;
   WgCtx<K> &c;
   int T;
+  // where entry `e` (an id below nRestore: what phase B re-stamps) is stored
+  SPICEY_HD void put_entry(uint32_t e, int k, double v) const {
+    if (HYB) {
+      if (e < (uint32_t)P.hyb_g0) c.G[(size_t)e * K + k] = v;
+      else c.W[(size_t)(e - (uint32_t)P.hyb_g0) * K + k] = v;
+    } else {
+      c.W[(size_t)e * K + k] = v;
+    }
+  }
   // Which of the beyond-resident-capacity loops of B / Z have any work (wave-uniform, fixed for the run).  On the
   // circuits the resident geometry is sized for they are all empty, yet each one costs a bound fetch, address
   // arithmetic and a branch: ~1200 cycles per step in Z alone before they were put behind one test.
@@ -826,7 +864,7 @@ struct TranPhases2 {
   // the diagnostics of SpiceyOptions.diagnostics are compiled into every geometry but the two-workgroups-per-CU one (NSV = 6:
   // 128 VGPRs and nothing to spare — with them that kernel spills, which the build refuses); the host keeps a handle with
   // the option out of that geometry
-  static constexpr bool DIAG = NSV != 6;
+  static constexpr bool DIAG = NSV != 6 && !HYB;  // (nor into the hybrid-workspace build, for the same reason)
   SPICEY_HD void set_remainders() {
     brem = (P.nRestore > NSV * T ? 1u : 0u) | (P.nDynX > 0 ? 2u : 0u) | (P.n > NEL * T ? 4u : 0u) | (P.nRowX > 0 ? 8u : 0u) |
            (P.nDynEnt > Regs::NDD * T ? 16u : 0u);
@@ -882,7 +920,14 @@ struct TranPhases2 {
     for (int k = 0; k < K; k++) {  // entries that no phase ever writes: stamped once per run
       const double *sv = R.statv + (size_t)c.inst[k] * P.nLU;
       SPICEY_NOUNROLL
-      for (int e = P.nRestore + tid; e < P.nLU; e += T) c.W[(size_t)e * K + k] = sv[e];
+      for (int e = P.nRestore + tid; e < P.nLU; e += T) {
+        if (HYB) {
+          if (e < P.nRestore + P.hyb_g2) c.G[(size_t)e * K + k] = sv[e];  // leaf-owned: read from the global array by phase U_0 / K_0
+          else c.W[(size_t)(e - P.hyb_g0 - P.hyb_g2) * K + k] = sv[e];
+        } else {
+          c.W[(size_t)e * K + k] = sv[e];
+        }
+      }
     }
     for (int k = 0; k < K; k++) {
       const size_t in = (size_t)c.inst[k];
@@ -930,7 +975,7 @@ struct TranPhases2 {
         if (fabs(v[k]) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
         v[k] = spicey_rcp(v[k]);
       }
-    for (int k = 0; k < K; k++) c.W[(size_t)e * K + k] = v[k];
+    for (int k = 0; k < K; k++) put_entry(e, k, v[k]);
   }
   SPICEY_HD void rhs_row(uint32_t r, uint32_t d0, uint32_t d1) const {
     double acc[K];
@@ -941,7 +986,7 @@ struct TranPhases2 {
         const uint32_t ix = (f[i] & 0x7fffu) - 1;
         for (int k = 0; k < K; k++) { const double t = c.u[(size_t)ix * K + k]; acc[k] = (f[i] & 0x8000u) ? acc[k] - t : acc[k] + t; }
       }
-    for (int k = 0; k < K; k++) c.W[(size_t)(P.nLU + r) * K + k] = acc[k];
+    for (int k = 0; k < K; k++) c.W[(size_t)(P.xoff + r) * K + k] = acc[k];
   }
 
   // ---- B: matrix = static + dynamic stamps; right-hand side -----------------------------------------
@@ -960,13 +1005,13 @@ struct TranPhases2 {
       if (SPICEY_WAVE_ANY((dd & 0x7fffffffu) != 0u)) {  // dynamic entries are numbered first: only the first slot(s) take this path
         if (!(dd >> 31)) stamp_entry(e, dd, rr.sv[j]);
       } else if (!(dd >> 31)) {
-        for (int k = 0; k < K; k++) c.W[(size_t)e * K + k] = rr.sv[j][k];
+        for (int k = 0; k < K; k++) put_entry(e, k, rr.sv[j][k]);
       }
     }
     for (int j = Regs::NDD; j < NSV; j++) {  // plain restores (a dynamic entry this far up is left to the loop below)
       const int e = tid + j * T;
       if (e >= P.nDynEnt && e < P.nRestore)
-        for (int k = 0; k < K; k++) c.W[(size_t)e * K + k] = rr.sv[j][k];
+        for (int k = 0; k < K; k++) put_entry((uint32_t)e, k, rr.sv[j][k]);
     }
     SPICEY_MARK(c, 8);
     if (brem & 16u)
@@ -1003,7 +1048,7 @@ struct TranPhases2 {
           if (fabs(v) < SPICEY_EPS && c.valid[k]) { c.flags[1] = 1; c.flags[2] = c.inst[k]; }
           v = spicey_rcp(v);
         }
-        c.W[(size_t)e * K + k] = v;
+        put_entry(e, k, v);
       }
     }
   }
@@ -1032,7 +1077,7 @@ struct TranPhases2 {
           const double t2 = c.u[(size_t)SPICEY_IDX(ix) * K + k];
           acc = (ix & SPICEY_NEG) ? acc - t2 : acc + t2;
         }
-        c.W[(size_t)(P.nLU + r) * K + k] = acc;
+        c.W[(size_t)(P.xoff + r) * K + k] = acc;
       }
     }
   }
@@ -1306,10 +1351,10 @@ SPICEY_HD void spicey_pcr_stage(const WgCtx<K> &c, double *buf, const uint16_t *
 // its instructions).  Every phase therefore takes the structs through `ex.fresh()`: on the GPU they live in global memory and
 // `fresh` makes their address opaque for this phase, so the fields a phase needs are fetched by scalar loads inside it
 // (scalar cache) and are dead at its barrier; only a handful of loop-control scalars stay live around the loop.
-template <int K, int RMAX, int NSV, int NEL, class Exec>
+template <int K, int RMAX, int NSV, int NEL, bool HYB = false, class Exec>
 SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyResident &Q, const SpiceyRun &R, WgCtx<K> &c, int wg) {
   const int T = ex.threads();
-  typedef TranPhases2<K, RMAX, NSV, NEL> Ph2;
+  typedef TranPhases2<K, RMAX, NSV, NEL, HYB> Ph2;
   uint32_t brem, zrem;
   {
     Ph2 p2{P, R, c, T, 0u, 0u};
@@ -1397,12 +1442,22 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
         ex.phase(SPICEY_PH_S, [&](int tid) {
           const SpiceyProg Pf = ex.fresh(P);
           const SpiceyRun Rf = ex.fresh(R);
-          spicey_skip_risk<K>(Pf, Rf, c, tid, T, linear ? (unsigned long long)(steps + 1) : 1ull);
+          spicey_skip_risk<K, HYB>(Pf, Rf, c, tid, T, linear ? (unsigned long long)(steps + 1) : 1ull);
         });
       for (int d = 0; d < dbg_empty; d++) ex.phase(SPICEY_PH_S, [&](int) {});  // diagnostics: cost of a bare phase
       // factor levels [0, u_end) | tail [u_end, k_begin) by one wave | backward levels [k_begin, 2 nL)
       for (int p = 0; p < u_end; p++) {
         if (p < 64 ? !((active >> p) & 1) : P.ph_cnt[p] == 0) continue;
+        if (HYB && p == 0) {
+          // hybrid workspace: phase 0 eliminates the leaves, whose own entries are read from the global array (one L2 round
+          // trip for the whole level; every target is in LDS)
+          ex.phase(SPICEY_PH_U0, [&](int tid) {
+            const SpiceyProg Pf = ex.fresh(P);
+            const SpiceyResident Qf = ex.fresh(Q);
+            spicey_uk_phase<K, RMAX, NSV, NEL, false, HYB>(Pf, Qf, c, ex.template regs<Regs>(tid), tid, T, 0, ((smask >> 0) & 1) != 0, linear && step > 0);
+          });
+          continue;
+        }
         ex.phase(SPICEY_PH_U0 + (p < 30 ? p : 30), [&](int tid) {
           const SpiceyProg Pf = ex.fresh(P);
           const SpiceyResident Qf = ex.fresh(Q);
@@ -1422,7 +1477,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
                       },
                       [&](int, int lvl, const uint32_t *r) {
                         const SpiceyProg Pf = ex.fresh(P);
-                        if (u_end + lvl < nL) spicey_exec_rec16<K, false>(c, Pf.ovf16, r[0], r[1], r[2], r[3], (linear && step > 0) ? (uint32_t)Pf.nLU : 0u);
+                        if (u_end + lvl < nL) spicey_exec_rec16<K, false>(c, Pf.ovf16, r[0], r[1], r[2], r[3], (linear && step > 0) ? (uint32_t)Pf.xoff : 0u);
                         else spicey_exec_rec16<K, true>(c, Pf.ovf16, r[0], r[1], r[2], r[3]);
                       });
       }
@@ -1441,7 +1496,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
         ex.phase(SPICEY_PH_K0, [&](int tid) {
           const SpiceyProg Pf = ex.fresh(P);
           const SpiceyResident Qf = ex.fresh(Q);
-          spicey_uk_phase<K, RMAX, NSV, NEL, true>(Pf, Qf, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);
+          spicey_uk_phase<K, RMAX, NSV, NEL, true, HYB>(Pf, Qf, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true);  // (level 0: the leaves)
           SPICEY_SCHED_FENCE;  // after the tasks, not among them: their registers are free by now
           if (K == 1) { const SpiceyRun Rf = ex.fresh(R); Ph2 p2{Pf, Rf, c, T, brem, zrem}; p2.z_prefetch(tid, step, 0, ex.template regs<Regs>(tid)); }
         });

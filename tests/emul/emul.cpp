@@ -110,6 +110,15 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
   for (int g = 0; g < ngroups; g++) {
     WgCtx<K> c;
     c.W = W.data(); c.u = u.data(); c.gd = gd.data(); c.ison = ison.data(); c.flags = flags.data(); c.tail = nullptr;
+    c.G = nullptr;
+    std::vector<double> Wl;  // hybrid: the LDS part only, sized exactly (the sanitizer build then catches an index into the part that moved out)
+    if (P.hybrid) {
+      Wl.assign((size_t)(P.nW - P.hyb_g0 - P.hyb_g2), 0.0);
+      c.W = Wl.data();
+      c.G = R.hyb_G + (size_t)g * (size_t)P.nLU;
+      c.u = R.hyb_ug + (size_t)g * (size_t)(P.nU + P.nGdyn);
+      c.gd = c.u + P.nU;
+    }
     for (int k = 0; k < K; k++) {
       int in = g * K + k;
       c.valid[k] = in < R.n_inst;
@@ -130,7 +139,19 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
       // NSV = 2 resident entries per thread: small on purpose so that tests also cover the streamed remainder
       // NEL = 2 resident elements / rows per thread: with the small T the tests use, the remainder loops run too.
       // rmax <= 8 takes the static-dispatch code path (RMAX = 8), larger the indexed-register path (RMAX = 16).
-      if (rmax <= 8) {
+      if (P.hybrid) {
+        if constexpr (K == 1) {
+          if (rmax <= 8) {
+            std::vector<ResRegs<K, 8, 2, 2>> regs(T);
+            ex.rr = &regs;
+            spicey_tran_run_v2<K, 8, 2, 2, true>(ex, P, Q, R, c, g);
+          } else {
+            std::vector<ResRegs<K, 16, 2, 2>> regs(T);
+            ex.rr = &regs;
+            spicey_tran_run_v2<K, 16, 2, 2, true>(ex, P, Q, R, c, g);
+          }
+        }
+      } else if (rmax <= 8) {
         std::vector<ResRegs<K, 8, 2, 2>> regs(T);
         ex.rr = &regs;
         spicey_tran_run_v2<K, 8, 2, 2>(ex, P, Q, R, c, g);
@@ -146,6 +167,8 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
 
 // diagnostics outputs of the NEXT spicey_emul_run (SpiceyOptions.diagnostics of the product): skip-risk counters [n_inst]
 // and per-step linearisation error [n_inst][steps + 1]; both optional, consumed by one run
+static int g_hybrid = 0;  // next runs: build the program with the hybrid workspace layout (v2 interpreter only)
+extern "C" void spicey_emul_set_hybrid(int32_t on) { g_hybrid = on; }
 static unsigned long long *g_diag_skip = nullptr;
 static double *g_diag_linerr = nullptr;
 extern "C" void spicey_emul_set_diag(unsigned long long *skip_risk, double *lin_err) { g_diag_skip = skip_risk; g_diag_linerr = lin_err; }
@@ -159,9 +182,11 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
   const int front_cut = reverse >> 8;  // bits 8..: elimination-tree level from which pivots are factored as dense fronts
   // bit 4: no tridiagonal top (the 16-bit records then cover every level); interleaved instances (K > 1) never use it
   // bit 5: streamed factor phases keep the generic records even where a row-record encoding exists
-  int32_t rc = spicey_build_program(d, hp, err, true, front_cut, !(reverse & 16) && K == 1);
+  const bool want_hyb = g_hybrid && rmax >= 0 && K == 1 && front_cut == 0;
+  int32_t rc = spicey_build_program(d, hp, err, true, front_cut, !(reverse & 16) && K == 1, want_hyb);
   if (rc != SPICEY_OK) return rc;
   SpiceyProg P = hp.bind(hp.blob.data());
+  if (want_hyb && !P.hybrid) return SPICEY_ERR_BAD_DESC;
   if (info) {
     memset(info, 0, sizeof(*info));
     info->n_var = P.n; info->nnz_a = hp.nnzA; info->nnz_lu = P.nLU; info->n_levels = P.nLevels;
@@ -171,6 +196,7 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
     info->n_workgroups = (d->n_inst + K - 1) / K;
     info->pcr_rows = (rmax >= 0 && K == 1) ? P.pcr_n : 0;
     info->pcr_level = info->pcr_rows ? P.pcr_level : 0;
+    info->hybrid_entries = P.hybrid ? P.hyb_g0 + P.hyb_g2 : 0;
   }
   if (hp.structurally_singular) {
     if (err4) { err4[0] = 1; err4[1] = 0; err4[2] = 0; err4[3] = 0; }
@@ -206,6 +232,12 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
     R.front_flags = front_flags.data();
     R.front_lds_doubles = (reverse & 8) ? 6144 : SPICEY_FRONT_LDS_DOUBLES;  // bit 3: force the staged path for fronts above 64 rows
     if (info) info->tail_levels = P.nFronts;  // (diagnostic: number of fronts)
+  }
+  std::vector<double> hybG, hybUG;
+  if (P.hybrid) {
+    hybG.assign((size_t)ni * (size_t)P.nLU, 0.0);
+    hybUG.assign((size_t)ni * (size_t)(P.nU + P.nGdyn + 1), 0.0);
+    R.hyb_G = hybG.data(); R.hyb_ug = hybUG.data();
   }
   std::vector<double> lin_vd((size_t)ni * (P.nD + 1), 0.0);
   if (g_diag_skip) { memset(g_diag_skip, 0, sizeof(unsigned long long) * (size_t)ni); R.skip_risk = g_diag_skip; }

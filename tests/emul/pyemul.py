@@ -47,7 +47,7 @@ def _p(a, t):
 
 
 class EmulBackend:
-    def __init__(self, K=1, T=256, reverse=False, rmax=-1, no_reuse=False, chain=False, front_cut=0, stage_fronts=False, ac_resident=False, no_pcr=False, no_rows=False, ac_no_dense=False, virt_wgs=1, diagnostics=0):
+    def __init__(self, K=1, T=256, reverse=False, rmax=-1, no_reuse=False, chain=False, front_cut=0, stage_fronts=False, ac_resident=False, no_pcr=False, no_rows=False, ac_no_dense=False, virt_wgs=1, diagnostics=0, hybrid=False):
         """rmax < 0: v1 interpreter (sliced-ELL, 32-bit); rmax >= 0: v2 with `rmax` register-resident slots.
         no_reuse: refactor every step even when the circuit is linear."""
         self.K, self.T, self.reverse, self.rmax, self.no_reuse = K, T, reverse, rmax, no_reuse
@@ -59,6 +59,7 @@ class EmulBackend:
         self.stage_fronts = stage_fronts  # dense fronts above 64 rows take the panel-staging (global workspace) path
         assert virt_wgs in (1, 3, 7, 21)
         self.virt_wgs = virt_wgs  # the subtree-local levels below a front cut are played as this many workgroups, one after the other
+        self.hybrid = hybrid  # v2 only: the hybrid workspace layout (leaf-owned entries and element vectors outside the "LDS" array)
         self.diagnostics = diagnostics  # bit 0: skip-risk counters, bit 1: per-step linearisation error (SpiceyOptions.diagnostics)
         self.front_cut = front_cut  # v1 only: pivots of elimination-tree level >= front_cut are factored as dense fronts
         self.info = None
@@ -80,6 +81,9 @@ class EmulBackend:
         solves = C.c_int64(0)
         skip = np.zeros(ni, np.uint64) if self.diagnostics & 1 else None
         linerr = np.zeros((ni, steps + 1)) if self.diagnostics & 2 else None
+        L.spicey_emul_set_hybrid.restype = None
+        L.spicey_emul_set_hybrid.argtypes = [C.c_int32]
+        L.spicey_emul_set_hybrid(1 if self.hybrid else 0)
         L.spicey_emul_set_diag.restype = None
         L.spicey_emul_set_diag.argtypes = [C.c_void_p, C.c_void_p]
         L.spicey_emul_set_diag(skip.ctypes.data if skip is not None else None, linerr.ctypes.data if linerr is not None else None)
@@ -87,6 +91,7 @@ class EmulBackend:
                                _p(out_i, C.c_double), _p(iters, C.c_int32), _p(st["C_vprev"], C.c_double),
                                _p(st["L_iprev"], C.c_double), _p(st["D_vdprev"], C.c_double), _p(st["S_ison"], C.c_int32),
                                (1 if self.reverse else 0) | (2 if self.no_reuse else 0) | (4 if self.chain else 0) | (8 if self.stage_fronts else 0) | (16 if self.no_pcr else 0) | (32 if self.no_rows else 0) | (64 if self.virt_wgs % 3 == 0 else 0) | (128 if self.virt_wgs % 7 == 0 else 0) | (int(self.front_cut) << 8), C.byref(info), _p(err4, C.c_int32), C.byref(solves), self.rmax)
+        L.spicey_emul_set_hybrid(0)
         self.info = info.as_dict()
         self.solves = solves.value
         detail = f"singular at inst {err4[1]} step {err4[2]} iter {err4[3]}" if rc == abi.ERR_SINGULAR else ""

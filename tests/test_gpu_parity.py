@@ -215,6 +215,47 @@ def test_beyond_resident_capacity(kind, n, oracle_backend):
         assert tol_ratio(got["state"][k], ref["state"][k]).max() <= 1.0
 
 
+@pytest.mark.parametrize("kind,n", [("diode_chain", 3000), ("rc_ladder", 3600), ("diode_chain", 2300)])
+def test_hybrid_workspace_beyond_the_lds_capacity(kind, n, oracle_backend):
+    """Circuits whose L+U no longer fits the LDS of one CU (from ~2 270 nodes on a chain) keep the 16-bit register-resident
+    interpreter: the entries the leaves of the elimination tree own and the element vectors live in global memory, the
+    upper tree and the right-hand side in LDS (SpiceyInfo.hybrid_entries; program.h).  Same tasks, same operands, same
+    order as the all-LDS layout: the CPU emulation of both layouts is bit-identical (test_program_emul.py); here the GPU
+    against the oracle at 3 000 nodes, against the 32-bit lists on the global workspace, and batched."""
+    from spicey_amd.lib import HipBackend
+    ckt = parseNetlist(getattr(synth, kind)(n, seed=7, tran=".tran 1e-6 2.5e-5"))
+    dt, steps = abi.computeEffectiveTimeStep(1e-6, 2.5e-5)
+    flat = abi.flatten(ckt)
+    src = abi.source_table(ckt, dt, steps)
+    be = HipBackend()
+    got = be.run(flat, steps, dt, src)
+    assert got["status"] == 0, got["detail"]
+    assert be.info["interpreter"] == 2 and be.info["hybrid_entries"] > 0.3 * be.info["nnz_lu"] and be.info["threads"] == 512
+    assert 0 < be.info["lds_bytes"] <= 160 * 1024 and be.info["wgs_per_inst"] == 1
+    ref = oracle_backend.run(flat, steps, dt, src)
+    assert tol_ratio(got["out_v"], ref["out_v"]).max() <= 1.0 and tol_ratio(got["out_i"], ref["out_i"]).max() <= 1.0
+    for k in ("C_vprev", "D_vdprev"):
+        assert tol_ratio(got["state"][k], ref["state"][k]).max() <= 1.0
+    old = HipBackend(interpreter=1)  # the path such circuits took before: 32-bit lists, global workspace, cooperating workgroups
+    o = old.run(flat, steps, dt, src)
+    assert old.info["hybrid_entries"] == 0 and old.info["lds_bytes"] == 0 and tol_ratio(o["out_v"], got["out_v"]).max() <= 1.0
+    if kind == "diode_chain" and n == 3000:
+        # a batch: one workgroup per instance, each with its own slice of the global arrays; a second run continues
+        from spicey_amd.lib import Handle
+        flats = [abi.flatten(parseNetlist(synth.diode_chain(n, seed=s, tran=".tran 1e-6 2.5e-5"))) for s in (7, 8, 9)]
+        h = Handle(abi.stack_instances(flats))
+        try:
+            assert h.info()["hybrid_entries"] > 0
+            a = h.run(steps, dt, src)
+            b = h.run(steps, dt, src)
+            assert a["status"] == 0 and b["status"] == 0 and np.array_equal(a["out_v"][0], got["out_v"][0])
+            r8 = oracle_backend.run(flats[1], steps, dt, src)
+            assert tol_ratio(a["out_v"][1], r8["out_v"][0]).max() <= 1.0
+            assert not np.array_equal(a["out_v"], b["out_v"])
+        finally:
+            h.close()
+
+
 def test_large_instance_global_workspace(oracle_backend):
     """rcd_mesh(34x34): L+U no longer fits the 160 KB LDS -> 32-bit task lists on a global (L2) workspace."""
     from spicey_amd.lib import HipBackend

@@ -134,6 +134,48 @@ def test_skip_risk_of_a_linear_circuit_counts_every_solve(oracle_backend):
         assert np.array_equal(a["out_v"], b["out_v"])
 
 
+@pytest.mark.parametrize("name", ["dchain20", "ladder20", "mesh6", "mesh9x5", "boost_probe", "half_bridge", "fv_chain", "star_hub", "relay_osc"])
+def test_hybrid_workspace_layout_is_bit_identical(name, oracle_backend):
+    """Hybrid workspace (program.h, SpiceyProg::hybrid): the entries the leaves of the elimination tree own and the element
+    vectors live OUTSIDE the LDS array (on the GPU: global memory; here: separate host arrays, the "LDS" one sized exactly,
+    so that the sanitizer build catches an index on the wrong side) and are read by factor phase 0 and the last backward
+    phase through their own operand path.  Same tasks, operands and order: bit-identical to the all-LDS layout, with and
+    without the tridiagonal top and the row records, both resident-slot code paths; and within the bar of the oracle."""
+    flat, steps, dt, src = _inputs(name)
+    ref = oracle_backend.run(flat, steps, dt, src)
+    ran = 0
+    for rmax in (8, 16):
+        for kw in (dict(), dict(no_pcr=True), dict(no_rows=True)):
+            plain = EmulBackend(1, 64, False, rmax, **kw).run(flat, steps, dt, src)
+            be = EmulBackend(1, 64, False, rmax, hybrid=True, **kw)
+            hy = be.run(flat, steps, dt, src)
+            if hy["status"] == abi.ERR_BAD_DESC:  # no hybrid layout for this circuit (fewer than three levels)
+                continue
+            ran += 1
+            assert hy["status"] == 0 and be.info["hybrid_entries"] > 0
+            for k in ("out_v", "out_i", "iters"):
+                assert np.array_equal(hy[k], plain[k], equal_nan=(k != "iters")), (name, rmax, kw, k)
+            for k in plain["state"]:
+                assert np.array_equal(hy["state"][k], plain["state"][k]), (name, k)
+            assert ratio(hy["out_v"], ref["out_v"]).max() <= 1.0
+    assert ran >= 4 or name in ("relay_osc",)
+
+
+def test_hybrid_workspace_layout_on_chains_and_reuse(oracle_backend):
+    """The shapes the layout is for: long chains (wide leaf level with row records, tridiagonal top), a linear ladder that
+    reuses its factors (phase 0 then runs its right-hand-side column only), reversed thread order inside every phase."""
+    for text in (synth.diode_chain(300, seed=4, tran=".tran 1e-6 1.5e-5"), synth.rc_ladder(260, seed=5, tran=".tran 1e-6 1.5e-5")):
+        ckt = parseNetlist(text)
+        dt, steps = abi.computeEffectiveTimeStep(ckt.analyses["tran"]["dt"], ckt.analyses["tran"]["tstop"])
+        flat, src = abi.flatten(ckt), abi.source_table(ckt, dt, steps)
+        plain = EmulBackend(1, 128, False, 8).run(flat, steps, dt, src)
+        for kw in (dict(), dict(reverse=True), dict(no_reuse=True)):
+            be = EmulBackend(1, 128, kw.get("reverse", False), 8, no_reuse=kw.get("no_reuse", False), hybrid=True)
+            hy = be.run(flat, steps, dt, src)
+            assert hy["status"] == 0 and be.info["hybrid_entries"] > 0.3 * be.info["nnz_lu"]
+            assert np.array_equal(hy["out_v"], plain["out_v"]) and np.array_equal(hy["out_i"], plain["out_i"])
+
+
 def test_bridge_rectifier_reference_is_ill_conditioned(oracle_backend):
     """Why bridge_rectifier gets a loose tolerance: the REFERENCE algorithm's own answer moves by
     > 1e-6 V when one diode's Is changes by 1e-15 relative (4 ulp), i.e. 1e-9 parity is undefined there."""
