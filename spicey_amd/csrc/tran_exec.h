@@ -744,6 +744,50 @@ SPICEY_HD void spicey_exec_row16(const WgCtx<K> &c, const uint32_t *w, bool rhs_
   }
 }
 
+// Two row records of the leaves' factor phase under the hybrid workspace (OPG): the global operands of BOTH are fetched first,
+// then each record runs exactly as spicey_exec_row16 would (same products, same order: the rows of one level are independent).
+template <int K>
+SPICEY_HD void spicey_exec_row16_x2(const WgCtx<K> &c, const uint32_t *wa, const uint32_t *wb, bool rhs_only) {
+  static_assert(K == 1, "hybrid workspace: one instance per workgroup");
+  const uint32_t *w2[2] = {wa, wb};
+  double gl[2][2], gdg[2][2], gu[2][2], gf[2][2];
+  SPICEY_UNROLL
+  for (int r = 0; r < 2; r++) {
+    const uint32_t *w = w2[r];
+    const uint32_t l0 = w[1] >> 16, d0 = w[2] & 0xffffu, u0 = w[2] >> 16, f0 = w[3] >> 16;
+    const uint32_t l1 = w[4] >> 16, d1 = w[5] & 0xffffu, u1 = w[5] >> 16, f1 = w[6] >> 16;
+    gl[r][0] = c.G[l0]; gdg[r][0] = c.G[d0]; gu[r][0] = c.G[u0]; gf[r][0] = c.G[f0];
+    gl[r][1] = c.G[l1]; gdg[r][1] = c.G[d1]; gu[r][1] = c.G[u1]; gf[r][1] = c.G[f1];
+  }
+  SPICEY_UNROLL
+  for (int r = 0; r < 2; r++) {
+    const uint32_t *w = w2[r];
+    const uint32_t meta = w[0] >> 16;
+    if (!(meta & (SPICEY_R16_VALID << 8))) continue;
+    const uint32_t iaa = w[0] & 0xffffu, iy = w[1] & 0xffffu;
+    const uint32_t y0 = w[3] & 0xffffu, t0 = w[4] & 0xffffu, y1 = w[6] & 0xffffu, t1 = w[7] & 0xffffu;
+    const bool two = (meta & 3u) == 2u, o0 = (meta >> 4) & 1u, o1 = (meta >> 5) & 1u;
+    double aii = c.W[iaa], yi = c.W[iy];
+    const double vy0 = c.W[y0], vy1 = c.W[y1], vt0 = c.W[t0], vt1 = c.W[t1];
+    const double m0 = -(gl[r][0] * gdg[r][0]), m1 = -(gl[r][1] * gdg[r][1]);
+    yi = fma(m0, vy0, yi);
+    aii = fma(m0, gu[r][0], aii);
+    const double y2 = fma(m1, vy1, yi), a2 = fma(m1, gu[r][1], aii);
+    yi = two ? y2 : yi;
+    aii = two ? a2 : aii;
+    c.W[iy] = yi;
+    if (!rhs_only) {
+      if (o0) c.W[t0] = fma(m0, gf[r][0], vt0);
+      if (two && o1) c.W[t1] = fma(m1, gf[r][1], vt1);
+      if (meta & (SPICEY_R16_RECIP << 8)) {
+        if (fabs(aii) < SPICEY_EPS && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
+        aii = spicey_rcp(aii);
+      }
+      c.W[iaa] = aii;
+    }
+  }
+}
+
 template <int K, int RMAX, int NSV, int NEL, bool KTASK, bool OPG = false>
 SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, const WgCtx<K> &c, ResRegs<K, RMAX, NSV, NEL> &rr, int tid,
                                int T, int p, bool streamed, bool reuse = false) {
@@ -802,6 +846,19 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
     // generic records of rows that do not fit the pattern
     const uint32_t npair = d_cnt;
     const uint32_t *pb = P.fus16 + (size_t)d_first * 4;
+    if constexpr (OPG) {
+      // (hybrid workspace: the leaves' own entries come from L2 — two row records at a time, both fetched before either is
+      // executed, so that the operand loads of the second are in flight under the first)
+      SPICEY_NOUNROLL
+      for (uint32_t j = (uint32_t)tid; j < npair; j += 2u * (uint32_t)T) {
+        const uint32_t j2 = j + (uint32_t)T;
+        const bool two = j2 < npair;
+        uint32_t wa[8], wb[8];
+        for (int i = 0; i < 8; i++) { wa[i] = pb[(size_t)j * 8 + i]; wb[i] = pb[(size_t)(two ? j2 : j) * 8 + i]; }
+        if (!two) wb[0] = 0u;  // (no VALID flag: nothing runs)
+        spicey_exec_row16_x2<K>(c, wa, wb, reuse);
+      }
+    } else
     SPICEY_NOUNROLL
     for (uint32_t j = (uint32_t)tid; j < npair; j += (uint32_t)T) {
       uint32_t w[8];
@@ -997,7 +1054,146 @@ struct TranPhases2 {
     if (!reuse) stamp_matrix(tid, rr);  // a linear circuit keeps the factors of step 0 in W
     rhs_rows(tid, rr);
   }
+  // ---- batched forms of the beyond-resident-capacity loops (HYB builds, K = 1) -------------------------------------------
+  // Hybrid workspace: circuits of several thousand unknowns on 512 threads — most entries lie beyond the resident slots, and
+  // one at a time each of them costs two or three DEPENDENT round trips to L2 (descriptor, static value, conductances).
+  // Four at a time, every load of a stage issued before the first is used (the registers are there: this build is not at
+  // the 128-register cap).  Same arithmetic per entry as stamp_entry.
+  SPICEY_HD void stamp_rest_batched(int tid) const {
+    const double *sv0 = R.statv + (size_t)c.inst[0] * P.nLU;
+    // dynamic entries beyond the descriptor slots: [NDD T, nDynEnt)
+    if (brem & 16u)
+    SPICEY_NOUNROLL
+    for (int e0 = tid + Regs::NDD * T; e0 < P.nDynEnt; e0 += 4 * T) {
+      uint32_t dd[4];
+      double v[4], ga[4], gb[4];
+      SPICEY_UNROLL
+      for (int b = 0; b < 4; b++) {
+        const int e = e0 + b * T;
+        const bool have = e < P.nDynEnt;
+        dd[b] = have ? P.ent_dd[e] : 0x80000000u;
+        v[b] = sv0[have ? e : e0];
+      }
+      SPICEY_UNROLL
+      for (int b = 0; b < 4; b++) {
+        const uint32_t f0 = dd[b] & 0x7fffu, f1 = (dd[b] >> 15) & 0x7fffu;
+        const bool on = !(dd[b] >> 31);
+        ga[b] = c.gd[(on && f0) ? (f0 & 0x3fffu) - 1 : 0u];
+        gb[b] = c.gd[(on && f1) ? (f1 & 0x3fffu) - 1 : 0u];
+      }
+      SPICEY_UNROLL
+      for (int b = 0; b < 4; b++) {
+        if (dd[b] >> 31) continue;
+        const uint32_t f0 = dd[b] & 0x7fffu, f1 = (dd[b] >> 15) & 0x7fffu;
+        double x = v[b];
+        if (f0) x = (f0 & 0x4000u) ? x - ga[b] : x + ga[b];
+        if (f1) x = (f1 & 0x4000u) ? x - gb[b] : x + gb[b];
+        if (dd[b] & (1u << 30)) {
+          if (fabs(x) < SPICEY_EPS && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
+          x = spicey_rcp(x);
+        }
+        put_entry((uint32_t)(e0 + b * T), 0, x);
+      }
+    }
+    // static update targets beyond the resident slots: plain copies of their static value, [max(NSV T, nDynEnt), nRestore)
+    if (brem & 1u) {
+      int e0 = tid + NSV * T;
+      if (e0 < P.nDynEnt) e0 += ((P.nDynEnt - e0 + T - 1) / T) * T;
+      SPICEY_NOUNROLL
+      for (; e0 < P.nRestore; e0 += 4 * T) {
+        double v[4];
+        SPICEY_UNROLL
+        for (int b = 0; b < 4; b++) v[b] = sv0[e0 + b * T < P.nRestore ? e0 + b * T : e0];
+        SPICEY_UNROLL
+        for (int b = 0; b < 4; b++)
+          if (e0 + b * T < P.nRestore) put_entry((uint32_t)(e0 + b * T), 0, v[b]);
+      }
+    }
+    if (brem & 2u)
+    SPICEY_NOUNROLL
+    for (int t = tid; t < P.nDynX; t += T) {  // entries with > 2 dynamic stamps (rare: kept one at a time)
+      const uint32_t et = P.dynx_ent[t], e = SPICEY_IDX(et);
+      double x = sv0[e];
+      for (uint32_t j = P.dynx_ptr[t]; j < P.dynx_ptr[t + 1]; j++) {
+        const uint32_t ix = P.dynx_idx[j];
+        const double g = c.gd[SPICEY_IDX(ix)];
+        x = (ix & SPICEY_NEG) ? x - g : x + g;
+      }
+      if (et & SPICEY_TGT_RECIP) {
+        if (fabs(x) < SPICEY_EPS && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
+        x = spicey_rcp(x);
+      }
+      put_entry(e, 0, x);
+    }
+  }
+  // right-hand-side rows beyond the resident ones, four at a time: descriptors, then all their (up to 16) contributions
+  SPICEY_HD void rhs_rest_batched(int tid) const {
+    SPICEY_NOUNROLL
+    for (int r0 = tid + NEL * T; r0 < P.n; r0 += 4 * T) {
+      uint32_t d[4][2];
+      double t[4][4];
+      SPICEY_UNROLL
+      for (int b = 0; b < 4; b++) {
+        const int r = r0 + b * T < P.n ? r0 + b * T : r0;
+        d[b][0] = P.row_desc[(size_t)r * 2]; d[b][1] = P.row_desc[(size_t)r * 2 + 1];
+        if (r0 + b * T >= P.n) d[b][1] = 0xFFFFFFFFu;
+      }
+      SPICEY_UNROLL
+      for (int b = 0; b < 4; b++) {
+        const bool on = d[b][1] != 0xFFFFFFFFu;
+        const uint32_t f[4] = {d[b][0] & 0xffffu, d[b][0] >> 16, d[b][1] & 0xffffu, d[b][1] >> 16};
+        SPICEY_UNROLL
+        for (int i = 0; i < 4; i++) t[b][i] = c.u[(on && f[i]) ? (f[i] & 0x7fffu) - 1 : 0u];
+      }
+      SPICEY_UNROLL
+      for (int b = 0; b < 4; b++) {
+        if (d[b][1] == 0xFFFFFFFFu) continue;
+        const uint32_t f[4] = {d[b][0] & 0xffffu, d[b][0] >> 16, d[b][1] & 0xffffu, d[b][1] >> 16};
+        double acc = 0.0;
+        SPICEY_UNROLL
+        for (int i = 0; i < 4; i++)
+          if (f[i]) acc = (f[i] & 0x8000u) ? acc - t[b][i] : acc + t[b][i];
+        c.W[(size_t)(P.xoff + r0 + b * T)] = acc;
+      }
+    }
+  }
+
   SPICEY_HD void stamp_matrix(int tid, Regs &rr) const {
+    if (HYB) {
+      // hybrid workspace: the conductances live in global memory — those of all descriptor slots are fetched together (one
+      // L2 round trip) before the first entry is formed; then the plain restores; then the batched rest
+      double ga[Regs::NDD], gb[Regs::NDD];
+      SPICEY_UNROLL
+      for (int j = 0; j < Regs::NDD; j++) {
+        uint32_t dd = rr.dd[j];
+        SPICEY_OPAQUE(dd);
+        const uint32_t f0 = dd & 0x7fffu, f1 = (dd >> 15) & 0x7fffu;
+        const bool on = !(dd >> 31);
+        ga[j] = c.gd[(on && f0) ? (f0 & 0x3fffu) - 1 : 0u];
+        gb[j] = c.gd[(on && f1) ? (f1 & 0x3fffu) - 1 : 0u];
+      }
+      SPICEY_UNROLL
+      for (int j = 0; j < Regs::NDD; j++) {
+        uint32_t dd = rr.dd[j];
+        SPICEY_OPAQUE(dd);
+        if (dd >> 31) continue;
+        const uint32_t f0 = dd & 0x7fffu, f1 = (dd >> 15) & 0x7fffu;
+        double x = rr.sv[j][0];
+        if (f0) x = (f0 & 0x4000u) ? x - ga[j] : x + ga[j];
+        if (f1) x = (f1 & 0x4000u) ? x - gb[j] : x + gb[j];
+        if (dd & (1u << 30)) {
+          if (fabs(x) < SPICEY_EPS && c.valid[0]) { c.flags[1] = 1; c.flags[2] = c.inst[0]; }
+          x = spicey_rcp(x);
+        }
+        put_entry((uint32_t)(tid + j * T), 0, x);
+      }
+      for (int j = Regs::NDD; j < NSV; j++) {
+        const int e = tid + j * T;
+        if (e >= P.nDynEnt && e < P.nRestore) put_entry((uint32_t)e, 0, rr.sv[j][0]);
+      }
+      stamp_rest_batched(tid);
+      return;
+    }
     for (int j = 0; j < Regs::NDD; j++) {
       const uint32_t e = (uint32_t)(tid + j * T);
       uint32_t dd = rr.dd[j];
@@ -1054,13 +1250,39 @@ struct TranPhases2 {
   }
   SPICEY_HD void rhs_rows(int tid, Regs &rr) const {
     SPICEY_MARK(c, 9);
+    if (HYB) {  // (the contributions of all resident rows in one round trip to the global element vector)
+      double t[NEL][4];
+      SPICEY_UNROLL
+      for (int j = 0; j < NEL; j++) {
+        uint32_t d0 = rr.rhs[j][0], d1 = rr.rhs[j][1];
+        SPICEY_OPAQUE(d0); SPICEY_OPAQUE(d1);
+        const bool on = d1 != 0xFFFFFFFFu;
+        const uint32_t f[4] = {d0 & 0xffffu, d0 >> 16, d1 & 0xffffu, d1 >> 16};
+        SPICEY_UNROLL
+        for (int i = 0; i < 4; i++) t[j][i] = c.u[(on && f[i]) ? (f[i] & 0x7fffu) - 1 : 0u];
+      }
+      SPICEY_UNROLL
+      for (int j = 0; j < NEL; j++) {
+        uint32_t d0 = rr.rhs[j][0], d1 = rr.rhs[j][1];
+        SPICEY_OPAQUE(d0); SPICEY_OPAQUE(d1);
+        if (d1 == 0xFFFFFFFFu) continue;
+        const uint32_t f[4] = {d0 & 0xffffu, d0 >> 16, d1 & 0xffffu, d1 >> 16};
+        double acc = 0.0;
+        SPICEY_UNROLL
+        for (int i = 0; i < 4; i++)
+          if (f[i]) acc = (f[i] & 0x8000u) ? acc - t[j][i] : acc + t[j][i];
+        c.W[(size_t)(P.xoff + tid + j * T)] = acc;
+      }
+    } else
     for (int j = 0; j < NEL; j++) {
       uint32_t d0 = rr.rhs[j][0], d1 = rr.rhs[j][1];
       SPICEY_OPAQUE(d0); SPICEY_OPAQUE(d1);
       if (d1 != 0xFFFFFFFFu) rhs_row((uint32_t)(tid + j * T), d0, d1);
     }
     SPICEY_MARK(c, 10);
-    if (brem & 4u)
+    if (HYB) {
+      if (brem & 4u) rhs_rest_batched(tid);
+    } else if (brem & 4u)
     SPICEY_NOUNROLL
     for (int r = tid + NEL * T; r < P.n; r += T) {
       const uint32_t d0 = P.row_desc[(size_t)r * 2], d1 = P.row_desc[(size_t)r * 2 + 1];
@@ -1238,14 +1460,81 @@ struct TranPhases2 {
       }
       SPICEY_MARK(c, 3);
       if ((SPICEY_EXP & 32) || !zrem) continue;
-      if (zrem & 1u)
+      if (HYB) {
+        // (hybrid workspace: four items of every kind at a time — indices and parameters of all four in flight before the
+        // first terminal voltage is read; the same arithmetic per item as the loops below)
+        if (zrem & 1u)
+        SPICEY_NOUNROLL
+        for (int i0 = tid + NEL * T; i0 < P.nOut; i0 += 4 * T) {
+          int32_t xi[4];
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++) xi[b] = P.out_x[i0 + b * T < P.nOut ? i0 + b * T : i0];
+          double v[4];
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++) v[b] = xi[b] < 0 ? 0.0 : c.W[(size_t)xi[b]];
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++)
+            if (i0 + b * T < P.nOut) SPICEY_STREAM_STORE(&ov[i0 + b * T], v[b]);
+        }
+        if (oi && (zrem & 2u))
+        SPICEY_NOUNROLL
+        for (int i0 = tid + NEL * T; i0 < P.nR; i0 += 4 * T) {
+          uint32_t ab[4];
+          double gg[4], dv[4];
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++) { const int i = i0 + b * T < P.nR ? i0 + b * T : i0; ab[b] = P.R_ab[i]; gg[b] = g[i]; }
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++) dv[b] = dv16(ab[b], k);
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++)
+            if (i0 + b * T < P.nR) SPICEY_STREAM_STORE(&oi[cR + i0 + b * T], dv[b] * gg[b]);
+        }
+        if (zrem & 4u)
+        SPICEY_NOUNROLL
+        for (int i0 = tid + NEL * T; i0 < P.nC; i0 += 4 * T) {  // beyond the resident capacity: vPrev lives in the state array
+          uint32_t ab[4];
+          double gc[4], vp[4], dv[4];
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++) {
+            const int i = i0 + b * T < P.nC ? i0 + b * T : i0;
+            ab[b] = P.C_ab[i]; gc[b] = g[P.nR + i]; vp[b] = R.C_vprev[in * P.nC + i];
+          }
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++) dv[b] = dv16(ab[b], k);
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++) {
+            const int i = i0 + b * T;
+            if (i >= P.nC) continue;
+            z_cap(i, dv[b], k, in, gc[b], oi, cC, vp[b], false);
+            R.C_vprev[in * P.nC + i] = vp[b];
+          }
+        }
+        if (zrem & 64u)
+        SPICEY_NOUNROLL
+        for (int i0 = tid + NEL * T; i0 < P.nD; i0 += 4 * T) {
+          uint32_t ab[4];
+          double is4[4], d0[4], d1[4], vd[4];
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++) {
+            const int i = i0 + b * T < P.nD ? i0 + b * T : i0;
+            const double *dp = R.dpar + (in * P.nD + i) * 2;
+            ab[b] = P.D_ab[i]; is4[b] = R.D_is[in * P.nD + i]; d0[b] = dp[0]; d1[b] = dp[1];
+          }
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++) vd[b] = dv16(ab[b], k);
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++)
+            if (i0 + b * T < P.nD) z_dio(i0 + b * T, vd[b], k, in, is4[b], d0[b], d1[b], oi, cD, oD, last);
+        }
+      }
+      if (!HYB && (zrem & 1u))
       SPICEY_NOUNROLL
       for (int i = tid + NEL * T; i < P.nOut; i += T) ov[i] = P.out_x[i] < 0 ? 0.0 : c.W[(size_t)P.out_x[i] * K + k];
-      if (oi && (zrem & 2u)) {
+      if (!HYB && oi && (zrem & 2u)) {
         SPICEY_NOUNROLL
         for (int i = tid + NEL * T; i < P.nR; i += T) oi[cR + i] = dv16(P.R_ab[i], k) * g[i];
       }
-      if (zrem & 4u)
+      if (!HYB && (zrem & 4u))
       SPICEY_NOUNROLL
       for (int i = tid + NEL * T; i < P.nC; i += T) {  // beyond the resident capacity: vPrev lives in the state array
         double vp = R.C_vprev[in * P.nC + i];
@@ -1277,7 +1566,7 @@ struct TranPhases2 {
         c.gd[(size_t)i * K + k] = gs;
         if (last) R.S_ison[in * P.nS + i] = on;
       }
-      if (zrem & 64u)
+      if (!HYB && (zrem & 64u))
       SPICEY_NOUNROLL
       for (int i = tid + NEL * T; i < P.nD; i += T) {
         const double *dp = R.dpar + (in * P.nD + i) * 2;
