@@ -275,6 +275,64 @@ struct FrontsRun {
 #endif
   }
 
+  // ---- LEFT-looking update of a block of a staged front: C[i][j] -= sum over the panels pj < npan, k < 16 of
+  //      L_pj[grow0 + i][k] * U[16 pj + k][gcol0 + j]   (i < nrow: a multiple of 16; j < ncol)
+  // L_pj = the multipliers of panel pj, kept in LDS for the whole front (Lall + loff(pj), rows counted from pivot 16 pj + 16,
+  // stride SPICEY_LPLD); U = the finished U rows in the front's block of the workspace (row stride ld).  C may be in LDS (the
+  // panel being formed) or in the workspace (the contribution block).  Same products in the same order per entry as the
+  // right-looking sweep (panel after panel, k ascending, the same MFMA tiling): bit-identical to it.
+  SPICEY_HD static int loff(int pj, int Mp) { return SPICEY_LPLD * pj * (Mp - SPICEY_FB - (SPICEY_FB / 2) * (pj - 1)); }
+  template <int NT = 2>
+  SPICEY_HD void trailing_left(double *C, int ldc, int nrow, int ncol, int npan, const double *Lall, int Mp, int grow0, const double *A, int ld, int gcol0,
+                               int t) const {
+    const int nw = T >> 6, w = t >> 6, lane = t & 63;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int tr = nrow >> 4, tc = (ncol + 15) >> 4;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int tile0 = w; tile0 < tr * tc; tile0 += NT * nw) {
+      double *c0[NT];
+      d4 acc[NT];
+      bool have[NT];
+      SPICEY_UNROLL
+      for (int b = 0; b < NT; b++) {
+        const int tile = tile0 + b * nw;
+        have[b] = tile < tr * tc;
+        const int tl = have[b] ? tile : tile0;
+        const int ti = tl / tc, tj = tl - ti * tc;
+        c0[b] = C + (size_t)(ti * 16 + lk) * ldc + tj * 16 + li;
+        acc[b][0] = c0[b][0]; acc[b][1] = c0[b][(size_t)4 * ldc]; acc[b][2] = c0[b][(size_t)8 * ldc]; acc[b][3] = c0[b][(size_t)12 * ldc];
+      }
+      for (int pj = 0; pj < npan; pj++) {
+        SPICEY_UNROLL
+        for (int b = 0; b < NT; b++) {
+          const int tile = have[b] ? tile0 + b * nw : tile0;
+          const int ti = tile / tc, tj = tile - ti * tc;
+          const double *la = Lall + loff(pj, Mp) + (size_t)(grow0 + ti * 16 + li - SPICEY_FB * pj - SPICEY_FB) * SPICEY_LPLD + lk;
+          const double *ub = A + (size_t)(SPICEY_FB * pj + lk) * ld + gcol0 + tj * 16 + li;
+          SPICEY_UNROLL
+          for (int kk = 0; kk < 4; kk++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[4 * kk], ub[(size_t)4 * kk * ld], acc[b], 0, 0, 0);
+        }
+      }
+      SPICEY_UNROLL
+      for (int b = 0; b < NT; b++)
+        if (have[b]) { c0[b][0] = acc[b][0]; c0[b][(size_t)4 * ldc] = acc[b][1]; c0[b][(size_t)8 * ldc] = acc[b][2]; c0[b][(size_t)12 * ldc] = acc[b][3]; }
+    }
+#else
+    const int nchunk = (ncol + 63) >> 6;
+    for (int pr = w; pr < nrow * nchunk; pr += nw) {
+      const int i = pr / nchunk, j = (pr - i * nchunk) * 64 + lane;
+      if (j >= ncol) continue;
+      double acc = C[(size_t)i * ldc + j];
+      for (int pj = 0; pj < npan; pj++) {
+        const double *l = Lall + loff(pj, Mp) + (size_t)(grow0 + i - SPICEY_FB * pj - SPICEY_FB) * SPICEY_LPLD;
+        for (int k = 0; k < SPICEY_FB; k++) acc = fma(-l[k], A[(size_t)(SPICEY_FB * pj + k) * ld + gcol0 + j], acc);
+      }
+      C[(size_t)i * ldc + j] = acc;
+    }
+#endif
+  }
+
   // ---- blocked partial LU of the first Pp pivots, front resident in LDS (row stride lda = Mp + 17) ----------------
   SPICEY_HD void factor_lds(const SpiceyFront &F, double *A, int lda, double *scr) const {
     double *Ld = scr, *Dinv = scr + SPICEY_FB * SPICEY_FB;
@@ -312,7 +370,67 @@ struct FrontsRun {
   }
 
   // ---- the same for a front that stays in the workspace: one panel at a time staged through LDS --------------------
+  // LEFT-looking form of the same factorisation, for staged fronts whose multipliers fit LDS (all of the 100 x 100 mesh's):
+  // the right-looking sweep below reads and writes the whole trailing block of the workspace once per panel (0.5 MB per
+  // panel of a 192-row front, at the 60 GB/s one CU gets from L2: 8 us of a 15.6 us panel); here a panel is staged into
+  // LDS, takes the updates of ALL earlier panels there (their multipliers stay in LDS, their U rows are read back from the
+  // workspace: 26 KB per earlier panel), is factored, and only its 16 U rows go back; the contribution block takes the
+  // products of all panels in ONE pass at the end.  Traffic per front: ~0.9 MB instead of ~3 MB.
+  SPICEY_HD int left_lds_need(const SpiceyFront &F) const {
+    return loff(F.Pp / SPICEY_FB, F.Mp) + SPICEY_FB * F.ld + SPICEY_FB * SPICEY_FB + SPICEY_FB;
+  }
+  SPICEY_HD void factor_global_left(const SpiceyFront &F) const {
+    double *A = FW + F.off;
+    double *lds = ex.lds();
+    const int Mp = F.Mp, ld = F.ld;
+    double *Lall = lds;                                   // multipliers of every panel, panel pj at loff(pj, Mp)
+    double *Up = Lall + loff(F.Pp / SPICEY_FB, Mp);       // the 16 pivot rows of the panel being formed, stride su
+    double *Ld = Up + (size_t)SPICEY_FB * ld, *Dinv = Ld + SPICEY_FB * SPICEY_FB;
+    for (int j0 = 0; j0 < F.Pp; j0 += SPICEY_FB) {
+      const int pj = j0 / SPICEY_FB;
+      const int su = ld - j0, wU = Mp + 1 - j0, nL = Mp - j0 - SPICEY_FB;
+      double *Lp = Lall + loff(pj, Mp);
+      ex.wg_phase([&](int t) {  // stage the panel: its 16 rows (from the diagonal block to the right-hand side), its column block below
+        const int nw = T >> 6, w = t >> 6, lane = t & 63;
+        for (int k = w; k < SPICEY_FB; k += nw) {
+          const double *src = A + (size_t)(j0 + k) * ld + j0;
+          for (int c = lane; c < su; c += 64) Up[(size_t)k * su + c] = src[c];
+        }
+        SPICEY_NOUNROLL
+        for (int i = t; i < nL * SPICEY_FB; i += T) {
+          const int r = i >> 4, k = i & 15;
+          Lp[(size_t)r * SPICEY_LPLD + k] = A[(size_t)(j0 + SPICEY_FB + r) * ld + j0 + k];
+        }
+      });
+      ex.mark(SPICEY_PH_U0 + 24);
+      if (pj > 0)
+        ex.wg_phase([&](int t) {  // the updates of all earlier panels, in panel order
+          trailing_left(Lp, SPICEY_LPLD, nL, SPICEY_FB, pj, Lall, Mp, j0 + SPICEY_FB, A, ld, j0, t);
+          trailing_left(Up, su, SPICEY_FB, wU, pj, Lall, Mp, j0, A, ld, j0, t);
+        });
+      ex.mark(SPICEY_PH_U0 + 27);
+      diag_block(Up, su, Ld, Dinv, F.p - j0);
+      ex.mark(SPICEY_PH_U0 + 25);
+      ex.wg_phase([&](int t) { panel_trsm(Up, su, Lp, SPICEY_LPLD, Ld, Dinv, nL, wU - SPICEY_FB, t); });
+      ex.mark(SPICEY_PH_U0 + 26);
+      ex.wg_phase([&](int t) {  // the finished U rows (reciprocal pivots on the diagonal) -> workspace
+        const int nw = T >> 6, w = t >> 6, lane = t & 63;
+        for (int k = w; k < SPICEY_FB; k += nw) {
+          double *dst = A + (size_t)(j0 + k) * ld + j0;
+          for (int c = lane; c < wU; c += 64) dst[c] = c == k ? Dinv[k] : Up[(size_t)k * su + c];
+        }
+      });
+      ex.mark(SPICEY_PH_U0 + 24);
+    }
+    // contribution block (rows and columns of the boundary, right-hand side included): every panel's products in one pass
+    if (Mp > F.Pp)
+      ex.wg_phase([&](int t) {
+        trailing_left<SPICEY_TRAIL_TILES_STAGED>(A + (size_t)F.Pp * ld + F.Pp, ld, Mp - F.Pp, Mp + 1 - F.Pp, F.Pp / SPICEY_FB, Lall, Mp, F.Pp, A, ld, F.Pp, t);
+      });
+    ex.mark(SPICEY_PH_U0 + 27);
+  }
   SPICEY_HD void factor_global(const SpiceyFront &F) const {
+    if (!R.front_right_looking && left_lds_need(F) <= SPICEY_FRONT_LDS_DOUBLES) { factor_global_left(F); return; }
     double *A = FW + F.off;
     double *lds = ex.lds();
     for (int j0 = 0; j0 < F.Pp; j0 += SPICEY_FB) {

@@ -32,17 +32,24 @@ __device__ __forceinline__ void gpu_wave_lockstep(int nlanes, int nsteps, F f) {
   __syncthreads();
 }
 
+// issue priorities of the phases of a kernel that shares its CU with a second workgroup (see GpuExecV2)
+#define SPICEY_PRIO_TOP 3
+#define SPICEY_PRIO_NARROW 2
+#define SPICEY_PRIO_WIDE_U 1
 template <class F>
-__device__ __forceinline__ void gpu_wave_lockstep_keep(int nlanes, int nsteps, F f) {
+__device__ __forceinline__ void gpu_wave_lockstep_keep(int nlanes, int nsteps, F f, bool prio = false) {
   int tid = (int)threadIdx.x;
   asm volatile("" : "+v"(tid));
   if (tid < 64) {
+    // the one wave on the critical path of its workgroup: ahead of the co-resident workgroup's waves in the issue arbitration
+    if (prio) __builtin_amdgcn_s_setprio(SPICEY_PRIO_TOP);
     double keep[4] = {0.0, 0.0, 0.0, 0.0};  // per-lane values that live in registers from step to step
     for (int s = 0; s < nsteps; s++) {
       if (tid < nlanes) f(tid, s, keep);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+    if (prio) __builtin_amdgcn_s_setprio(0);
   }
   __syncthreads();
 }
@@ -392,7 +399,12 @@ __global__ void __launch_bounds__(FRONTS ? 512 : 1024) spicey_tran_kernel_grp(Sp
 }
 
 // v2: register-resident program (LDS workspace only; 16-bit records)
-template <class Regs>
+// PRIO: the kernel is built for two workgroups per CU (the packed geometry), which run different phases at the same moment.
+// The issue arbitration then favours the phase that has less to hide its latency behind: 3 for the tridiagonal top (one
+// wave, a dependent chain), 2 for the narrow levels (backward levels, factor levels from the third on: one short task per
+// lane or none), 1 for the two wide factor levels, 0 for stamping and the update (wide, throughput-bound).  Measured on the
+// headline batch: 3.91e7 -> 4.05e7 solves/s; a lone workgroup per CU gains nothing (9.86 -> 10.1 us), so it is off there.
+template <class Regs, bool PRIO = false>
 struct GpuExecV2 {
   unsigned long long *prof;  // LDS accumulators [SPICEY_PH_SLOTS] when profiling, else null
   long long t_last = 0;      // profiling: end of the previous phase (slot 7 accumulates the time BETWEEN phases)
@@ -429,7 +441,7 @@ struct GpuExecV2 {
   __device__ __forceinline__ void wave_lockstep_keep(int nlanes, int nsteps, F f) {
     long long t0 = 0;
     if (prof && threadIdx.x == 0) { t0 = clock64(); if (t_last) atomicAdd(&prof[7], (unsigned long long)(t0 - t_last)); }
-    gpu_wave_lockstep_keep(nlanes, nsteps, f);
+    gpu_wave_lockstep_keep(nlanes, nsteps, f, PRIO);
     if (prof && threadIdx.x == 0) { t_last = clock64(); atomicAdd(&prof[SPICEY_PH_U0 + 31], (unsigned long long)(t_last - t0)); }
   }
   template <class L, class F>
@@ -460,7 +472,11 @@ struct GpuExecV2 {
     // pair per array and instance) out of the time loop and the register-resident program spills.
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
+    const int pr = !PRIO ? 0 : tag >= SPICEY_PH_U0 + 2 ? SPICEY_PRIO_NARROW : tag >= SPICEY_PH_U0 ? SPICEY_PRIO_WIDE_U : 0;  // (uniform: an SGPR)
+    if (pr == SPICEY_PRIO_NARROW) __builtin_amdgcn_s_setprio(SPICEY_PRIO_NARROW);
+    if (pr == SPICEY_PRIO_WIDE_U) __builtin_amdgcn_s_setprio(SPICEY_PRIO_WIDE_U);
     f(tid);
+    if (pr) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     if (prof && threadIdx.x == 0) { t_last = clock64(); atomicAdd(&prof[tag], (unsigned long long)(t_last - t0)); }  // LDS: no stall
   }
@@ -498,7 +514,7 @@ __global__ void __launch_bounds__(MAXT, MINW) spicey_tran_kernel_v2(const Spicey
     c.ison = (int32_t *)(c.gd + nG);
   }
   c.flags = c.ison + (size_t)P.nS * K;
-  GpuExecV2<ResRegs<K, RMAX, NSV, NEL>> ex;
+  GpuExecV2<ResRegs<K, RMAX, NSV, NEL>, (MINW * 256 >= 2 * MAXT)> ex;  // two workgroups per CU
   // profiling accumulators live in LDS behind the flags (576 B, reserved by spicey_lds_bytes)
   // (offsets from `smem`, no integer casts: the pointers must keep their LDS address space, or every access
   // becomes a flat_load)

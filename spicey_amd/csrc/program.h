@@ -262,6 +262,7 @@ struct SpiceyRun {
   double *front_ws;
   const uint32_t *fs_first, *fs_list, *fs_owner;  // fs_owner[nFronts]: workgroup (of the group) that runs a front
   unsigned int *front_flags;
+  int32_t front_right_looking; // experiments / tests: staged fronts take the right-looking sweep (a trailing update of the workspace per panel) even where the left-looking one fits
   int32_t front_lds_doubles;  // LDS scratch per workgroup (fronts that fit live there whole; tests shrink it to force the staged path)
   int32_t force_abort;        // tests: group mode raises its abort word at start-up (exercises the host's one relaunch)
   // group mode: longest single cross-workgroup wait, in ticks of the chip-wide 100 MHz counter, before the launch aborts

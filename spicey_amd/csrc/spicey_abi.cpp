@@ -608,7 +608,8 @@ extern "C" int32_t spicey_run_device(SpiceyHandle *h, int64_t steps, double dt, 
     R.fs_list = h->d_fs + (h->G + 1);
     R.fs_owner = R.fs_list + h->hp.hdr.nFronts;
     R.front_flags = h->d_front_flags;
-    R.front_lds_doubles = (h->opt.debug & 8) ? 6144 : SPICEY_FRONT_LDS_DOUBLES;  // diagnostics: bit 3 = stage every front above 64 rows through panels
+    R.front_lds_doubles = (h->opt.debug & 8) ? 6144 : SPICEY_FRONT_LDS_DOUBLES;
+    R.front_right_looking = getenv("SPICEY_FRONT_RIGHT_LOOKING") != nullptr ? 1 : 0;  // experiments: the round-2 sweep of staged fronts  // diagnostics: bit 3 = stage every front above 64 rows through panels
     HIPCHK(h, hipMemsetAsync(h->d_front_flags, 0, (size_t)h->grid * 2 * (size_t)h->hp.hdr.nFronts * sizeof(unsigned int), st));
   }
   if (h->G > 1) {

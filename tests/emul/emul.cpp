@@ -230,7 +230,8 @@ extern "C" int32_t spicey_emul_run(const SpiceyDesc *d, int32_t K, int32_t T, in
     front_flags.assign((size_t)ngroups * 2 * P.nFronts, 0u);
     R.front_ws = front_ws.data(); R.fs_first = fs_first.data(); R.fs_list = fs_list.data(); R.fs_owner = fs_owner.data();
     R.front_flags = front_flags.data();
-    R.front_lds_doubles = (reverse & 8) ? 6144 : SPICEY_FRONT_LDS_DOUBLES;  // bit 3: force the staged path for fronts above 64 rows
+    R.front_lds_doubles = (reverse & 8) ? 6144 : SPICEY_FRONT_LDS_DOUBLES;
+    R.front_right_looking = getenv("SPICEY_FRONT_RIGHT_LOOKING") != nullptr ? 1 : 0;  // bit 3: force the staged path for fronts above 64 rows
     if (info) info->tail_levels = P.nFronts;  // (diagnostic: number of fronts)
   }
   std::vector<double> hybG, hybUG;
