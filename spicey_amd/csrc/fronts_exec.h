@@ -127,31 +127,66 @@ struct FrontsRun {
   SPICEY_HD void diag_block(double *Up, int su, double *Ld, double *Dinv, int npiv_real) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     // wave 0, lane = (row i = lane / 4, column residue jq = lane % 4): the lane's four entries stay in registers for all
-    // 16 elimination steps; the pivot, the row's multiplier source and the pivot row travel by cross-lane shuffles
+    // 16 elimination steps.  ONE wave issues an instruction every ~4.5 cycles, whatever it is (measured: 60 instructions per
+    // step = 270 cycles with every cross-lane hop removed) — so the step is written for instruction count first: rows and
+    // columns that a step leaves alone are masked by ONE exec-mask block per step (not a select pair per value), the
+    // reciprocal pivots and the singularity verdict are kept in registers and leave once, at the end.  Second, the hops on
+    // the chain pivot -> reciprocal -> multiplier -> update -> next pivot take the shortest path the hardware has: the
+    // pivot is wave-uniform (v_readlane), the multiplier's source is in the lane's own quad (DPP quad_perm: a VALU move),
+    // and only the pivot row goes through the LDS crossbar (ds_bpermute), issued ahead of the reciprocal.
     ex.wg_phase([&](int t) {
       if (t >= 64) return;
       const int i = t >> 2, jq = t & 3;
       double a[4];
+#ifdef SPICEY_DIAG_TIMING
+      const long long c0 = clock64();
+#endif
 #pragma unroll
       for (int m = 0; m < 4; m++) a[m] = Up[(size_t)i * su + jq + 4 * m];
+#ifdef SPICEY_DIAG_TIMING
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const long long c1 = clock64();
+#endif
+      double dkeep = 0.0;  // lane k < 16 keeps 1 / pivot k
+      double pmin = 1.0;   // smallest |pivot| so far (the identity padding behind the real rows has pivots of exactly 1)
+      double *Lrow = Ld + i * SPICEY_FB;
 #pragma unroll
       for (int k = 0; k < SPICEY_FB; k++) {
-        const double piv = __shfl(a[k >> 2], (k << 2) | (k & 3));
-        const double d = spicey_rcp(piv);
-        const double l = __shfl(a[k >> 2], (t & ~3) | (k & 3)) * d;
-        if (t == 0) {
-          if (fabs(piv) < SPICEY_EPS && k < npiv_real && valid) { flags[1] = 1; flags[2] = inst; }  // solveReal.ts:28
-          Dinv[k] = d;
-        }
-        if (jq == 0 && i > k) Ld[i * SPICEY_FB + k] = l;
+        // the pivot row first; the register that holds the NEXT pivot leads, so that its update is the first to finish
+        const int m0 = k + 1 < SPICEY_FB ? (k + 1) >> 2 : 3;
+        double u[4];
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-          const double u = __shfl(a[m], (k << 2) | jq);
-          if (i > k && jq + 4 * m > k) a[m] = fma(-l, u, a[m]);
+        for (int mm = 0; mm < 4; mm++) {
+          const int m = (m0 + mm) & 3;
+          u[m] = 4 * m + 3 > k ? __shfl(a[m], (k << 2) | jq) : 0.0;  // (columns <= k: nothing to update)
         }
+        SPICEY_SCHED_FENCE;
+        const double piv = spicey_readlane_f64(a[k >> 2], (k << 2) | (k & 3));
+        const double d = spicey_rcp(piv);
+        pmin = fmin(pmin, fabs(piv));
+        dkeep = t == k ? d : dkeep;
+        const double l = spicey_quad_bcast_f64(a[k >> 2], k & 3) * d;
+        if (i > k) {  // (the store keeps this a branch: the updates inside run under its exec mask)
+          Lrow[k] = l;  // (the four lanes of the row's quad write the same value)
+#pragma unroll
+          for (int mm = 0; mm < 4; mm++) {
+            const int m = (m0 + mm) & 3;
+            if (4 * m > k) a[m] = fma(-l, u[m], a[m]);
+            else if (4 * m + 3 > k) a[m] = jq > (k & 3) ? fma(-l, u[m], a[m]) : a[m];  // the register that holds column k itself
+          }
+        }
+        SPICEY_SCHED_FENCE;
       }
+#ifdef SPICEY_DIAG_TIMING
+      const long long c2 = clock64();
+#endif
+      if (t < SPICEY_FB) Dinv[t] = dkeep;
+      if (t == 0 && pmin < SPICEY_EPS && valid) { flags[1] = 1; flags[2] = inst; }  // solveReal.ts:28
 #pragma unroll
       for (int m = 0; m < 4; m++) Up[(size_t)i * su + jq + 4 * m] = a[m];
+#ifdef SPICEY_DIAG_TIMING
+      if (t == 0 && ex.prof) { ex.prof[60] += (unsigned long long)(c1 - c0); ex.prof[61] += (unsigned long long)(c2 - c1); ex.prof[62] += (unsigned long long)(clock64() - c2); ex.prof[63] += 1; }
+#endif
     });
 #else
     // the same arithmetic with the block in memory: one wave in lockstep, step k eliminates column k
@@ -228,35 +263,45 @@ struct FrontsRun {
   // Device: 16 x 16 tiles, four v_mfma_f64_16x16x4 each (A = -L tile, B = U tile; operand maps: lane l holds A[l & 15][l >> 4]
   // and B[l >> 4][l & 15], result register r holds C[(l >> 4) + 4 r][l & 15]); the columns up to the next multiple of 16
   // exist behind C and the U panel (zero padding, left unchanged).  Host: the plain sum, k ascending.
-  template <int NT = 4>
+  template <int NT = 2>
   SPICEY_HD void trailing(double *C, int ldc, const double *Lp, int lpld, const double *Up, int su, int nrow, int ncol, int t) const {
     const int nw = T >> 6, w = t >> 6, lane = t & 63;
 #if defined(__HIP_DEVICE_COMPILE__)
+    // Written for instruction count (a wave issues one instruction per ~4.5 cycles): the tile walk of a wave is kept in
+    // scalar registers and advances without a division, the lane-dependent parts of the three operand addresses are formed
+    // once per call, and all 12 operand loads of a tile (NT tiles per turn) are issued before its first MFMA — one exposed
+    // LDS / L2 round trip per turn instead of one per MFMA (the first version: ~75 instructions and 4 round trips per tile).
     typedef double d4 __attribute__((ext_vector_type(4)));
+    const int ws = SPICEY_UNIFORM(w);
     const int tr = nrow >> 4, tc = (ncol + 15) >> 4;
     const int li = lane & 15, lk = lane >> 4;
-    // NT tiles per turn: their 4 NT C loads are in flight together before the first MFMA needs one
-    for (int tile0 = w; tile0 < tr * tc; tile0 += NT * nw) {
+    double *cl = C + (size_t)lk * ldc + li;          // + (16 ti + 4 r) ldc + 16 tj
+    const double *al = Lp + (size_t)li * lpld + lk;  // + 16 ti lpld + 4 kk
+    const double *bl = Up + (size_t)lk * su + li;    // + 4 kk su + 16 tj
+    const int dti = nw / tc, dtj = nw - dti * tc;    // the step from one tile of this wave to its next (row-major walk)
+    int ti = ws / tc, tj = ws - ti * tc;
+    while (ti < tr) {
       double *c0[NT];
-      d4 acc[NT];
+      d4 acc[NT], av[NT], bv[NT];
       bool have[NT];
       SPICEY_UNROLL
       for (int b = 0; b < NT; b++) {
-        const int tile = tile0 + b * nw;
-        have[b] = tile < tr * tc;
-        const int tl = have[b] ? tile : tile0;
-        const int ti = tl / tc, tj = tl - ti * tc;
-        c0[b] = C + (size_t)(ti * 16 + lk) * ldc + tj * 16 + li;
+        have[b] = ti < tr;  // (wave-uniform; an absent tile repeats the turn's first one and is not stored)
+        const int ui = have[b] ? ti : 0, uj = have[b] ? tj : 0;
+        c0[b] = cl + ((size_t)ui * 16 * ldc + (size_t)uj * 16);
+        const double *la = al + (size_t)ui * 16 * lpld;
+        const double *ub = bl + (size_t)uj * 16;
         acc[b][0] = c0[b][0]; acc[b][1] = c0[b][(size_t)4 * ldc]; acc[b][2] = c0[b][(size_t)8 * ldc]; acc[b][3] = c0[b][(size_t)12 * ldc];
+        av[b][0] = la[0]; av[b][1] = la[4]; av[b][2] = la[8]; av[b][3] = la[12];
+        bv[b][0] = ub[0]; bv[b][1] = ub[(size_t)4 * su]; bv[b][2] = ub[(size_t)8 * su]; bv[b][3] = ub[(size_t)12 * su];
+        tj += dtj; ti += dti;
+        if (tj >= tc) { tj -= tc; ti++; }
       }
+      SPICEY_SCHED_FENCE;
       SPICEY_UNROLL
       for (int b = 0; b < NT; b++) {
-        const int tile = have[b] ? tile0 + b * nw : tile0;
-        const int ti = tile / tc, tj = tile - ti * tc;
-        const double *la = Lp + (size_t)(ti * 16 + li) * lpld + lk;
-        const double *ub = Up + (size_t)lk * su + tj * 16 + li;
         SPICEY_UNROLL
-        for (int kk = 0; kk < 4; kk++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[4 * kk], ub[(size_t)4 * kk * su], acc[b], 0, 0, 0);
+        for (int kk = 0; kk < 4; kk++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[b][kk], bv[b][kk], acc[b], 0, 0, 0);
       }
       SPICEY_UNROLL
       for (int b = 0; b < NT; b++)
@@ -287,32 +332,62 @@ struct FrontsRun {
                                int t) const {
     const int nw = T >> 6, w = t >> 6, lane = t & 63;
 #if defined(__HIP_DEVICE_COMPILE__)
+    // (instruction economy as in trailing(): scalar tile walk, lane parts of the addresses formed once.)  The operands of
+    // panel pj + 1 are fetched before the MFMAs of panel pj are issued (two register sets, used alternately): the U rows come
+    // from the workspace (L2), and one exposed round trip per panel and turn was most of this update's time.
     typedef double d4 __attribute__((ext_vector_type(4)));
+    const int ws = SPICEY_UNIFORM(w);
     const int tr = nrow >> 4, tc = (ncol + 15) >> 4;
     const int li = lane & 15, lk = lane >> 4;
-    for (int tile0 = w; tile0 < tr * tc; tile0 += NT * nw) {
+    double *cl = C + (size_t)lk * ldc + li;
+    const double *al = Lall + (size_t)(grow0 + li - SPICEY_FB) * SPICEY_LPLD + lk;  // + 16 ti LPLD + [loff(pj) - 16 pj LPLD] + 4 kk
+    const double *bl = A + (size_t)lk * ld + gcol0 + li;                            // + 16 pj ld + 16 tj + 4 kk ld
+    const int dti = nw / tc, dtj = nw - dti * tc;
+    int ti = ws / tc, tj = ws - ti * tc;
+    while (ti < tr) {
       double *c0[NT];
-      d4 acc[NT];
+      const double *la[NT], *ub[NT];
+      d4 acc[NT], av[2][NT], bv[2][NT];
       bool have[NT];
       SPICEY_UNROLL
       for (int b = 0; b < NT; b++) {
-        const int tile = tile0 + b * nw;
-        have[b] = tile < tr * tc;
-        const int tl = have[b] ? tile : tile0;
-        const int ti = tl / tc, tj = tl - ti * tc;
-        c0[b] = C + (size_t)(ti * 16 + lk) * ldc + tj * 16 + li;
+        have[b] = ti < tr;
+        const int ui = have[b] ? ti : 0, uj = have[b] ? tj : 0;
+        c0[b] = cl + ((size_t)ui * 16 * ldc + (size_t)uj * 16);
+        la[b] = al + (size_t)ui * 16 * SPICEY_LPLD;
+        ub[b] = bl + (size_t)uj * 16;
         acc[b][0] = c0[b][0]; acc[b][1] = c0[b][(size_t)4 * ldc]; acc[b][2] = c0[b][(size_t)8 * ldc]; acc[b][3] = c0[b][(size_t)12 * ldc];
+        tj += dtj; ti += dti;
+        if (tj >= tc) { tj -= tc; ti++; }
       }
-      for (int pj = 0; pj < npan; pj++) {
+      auto fetch = [&](int set, int lo) {  // lo = loff(pj) - 16 pj LPLD
         SPICEY_UNROLL
         for (int b = 0; b < NT; b++) {
-          const int tile = have[b] ? tile0 + b * nw : tile0;
-          const int ti = tile / tc, tj = tile - ti * tc;
-          const double *la = Lall + loff(pj, Mp) + (size_t)(grow0 + ti * 16 + li - SPICEY_FB * pj - SPICEY_FB) * SPICEY_LPLD + lk;
-          const double *ub = A + (size_t)(SPICEY_FB * pj + lk) * ld + gcol0 + tj * 16 + li;
-          SPICEY_UNROLL
-          for (int kk = 0; kk < 4; kk++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[4 * kk], ub[(size_t)4 * kk * ld], acc[b], 0, 0, 0);
+          const double *x = la[b] + lo;
+          av[set][b][0] = x[0]; av[set][b][1] = x[4]; av[set][b][2] = x[8]; av[set][b][3] = x[12];
+          bv[set][b][0] = ub[b][0]; bv[set][b][1] = ub[b][(size_t)4 * ld]; bv[set][b][2] = ub[b][(size_t)8 * ld]; bv[set][b][3] = ub[b][(size_t)12 * ld];
+          ub[b] += (size_t)SPICEY_FB * ld;
         }
+      };
+      auto mult = [&](int set) {
+        SPICEY_UNROLL
+        for (int b = 0; b < NT; b++) {
+          SPICEY_UNROLL
+          for (int kk = 0; kk < 4; kk++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[set][b][kk], bv[set][b][kk], acc[b], 0, 0, 0);
+        }
+      };
+      int lo = 0;  // loff(pj, Mp) - 16 pj LPLD, advanced by LPLD (Mp - 32 - 16 pj) per panel
+      if (npan > 0) fetch(0, lo);
+      for (int pj = 0; pj < npan; pj += 2) {
+        lo += SPICEY_LPLD * (Mp - 2 * SPICEY_FB - SPICEY_FB * pj);
+        if (pj + 1 < npan) fetch(1, lo);
+        SPICEY_SCHED_FENCE;
+        mult(0);
+        if (pj + 1 >= npan) break;
+        lo += SPICEY_LPLD * (Mp - 2 * SPICEY_FB - SPICEY_FB * (pj + 1));
+        if (pj + 2 < npan) fetch(0, lo);
+        SPICEY_SCHED_FENCE;
+        mult(1);
       }
       SPICEY_UNROLL
       for (int b = 0; b < NT; b++)
@@ -425,7 +500,7 @@ struct FrontsRun {
     // contribution block (rows and columns of the boundary, right-hand side included): every panel's products in one pass
     if (Mp > F.Pp)
       ex.wg_phase([&](int t) {
-        trailing_left<SPICEY_TRAIL_TILES_STAGED>(A + (size_t)F.Pp * ld + F.Pp, ld, Mp - F.Pp, Mp + 1 - F.Pp, F.Pp / SPICEY_FB, Lall, Mp, F.Pp, A, ld, F.Pp, t);
+        trailing_left(A + (size_t)F.Pp * ld + F.Pp, ld, Mp - F.Pp, Mp + 1 - F.Pp, F.Pp / SPICEY_FB, Lall, Mp, F.Pp, A, ld, F.Pp, t);
       });
     ex.mark(SPICEY_PH_U0 + 27);
   }
@@ -468,70 +543,106 @@ struct FrontsRun {
   }
 
   // ---- backward substitution of one front -----------------------------------------------------------------
-  SPICEY_HD void load_db(const SpiceyFront &F, const double *A, double *Db, int t, int b0) const {
-    // (rows [p, Pp) of the pivot block are identity padding: an LDS-resident front never stores them)
-    for (int e = t; e < SPICEY_FB * SPICEY_FB; e += T) {
-      const int r = b0 + (e >> 4), cc = b0 + (e & 15);
-      Db[e] = r < F.p ? A[(size_t)r * F.ld + cc] : (r == cc ? 1.0 : 0.0);
-    }
+  // Own data first (right-hand side after the forward sweep, the U rows): this part does not need the ancestors' unknowns and
+  // runs BEFORE the front waits for its parent's workgroup; then the boundary product straight from W.
+  // The front's U rows (pivot block and boundary block, p x Mp) are copied into LDS in that first part when they fit (every
+  // front of the 100 x 100 mesh: at most 127 x 128): the block loop below then has no workspace (L2) round trip on its
+  // dependent chain — 8 blocks x (16 lock-step LDS round trips + a strided global read of 16 columns) were 25 us on the root.
+  // solve16: the 16 unknowns of one diagonal block.  Device: lane = row, its right-hand side and its row of the block in
+  // registers, the solved unknown travels by v_readlane (35 cycles per step against 190 through LDS); host: the same
+  // operations with the block in memory.
+  SPICEY_HD void solve16(const double *Ub, int lub, int b0, int p, double *tt, double *xs) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    ex.wg_phase([&](int t) {
+      if (t >= SPICEY_FB) return;
+      const int r = b0 + t;
+      double db[SPICEY_FB];
+      SPICEY_UNROLL
+      for (int k = 0; k < SPICEY_FB; k++) db[k] = r < p ? Ub[(size_t)t * lub + k] : (t == k ? 1.0 : 0.0);  // (rows [p, Pp): identity padding)
+      double tv = tt[r], xv = 0.0;
+      SPICEY_UNROLL
+      for (int k = SPICEY_FB - 1; k >= 0; k--) {
+        const double x = spicey_readlane_f64(tv * db[k], k);
+        if (t == k) xv = x;
+        if (t < k) tv = fma(-db[k], x, tv);
+      }
+      xs[r] = xv;
+    });
+#else
+    // one wave, 16 lanes in lockstep: step s solves x of row k = 15 - s and removes it from the rows above it
+    ex.wave_lockstep(SPICEY_FB, SPICEY_FB, [&](int lane, int s2) {
+      const int k = SPICEY_FB - 1 - s2;
+      if (lane > k) return;
+      const double dkk = b0 + k < p ? Ub[(size_t)k * lub + k] : 1.0;
+      const double x = tt[b0 + k] * dkk;
+      if (lane == k) xs[b0 + k] = x;
+      else tt[b0 + lane] = fma(-(b0 + lane < p ? Ub[(size_t)lane * lub + k] : 0.0), x, tt[b0 + lane]);
+    });
+#endif
   }
-  // Own data first (right-hand side after the forward sweep, last diagonal block): this part does not need the ancestors'
-  // unknowns and runs BEFORE the front waits for its parent's workgroup; then the boundary product straight from W.
   SPICEY_HD void solve(const SpiceyFront &F, bool wait_parent, unsigned int epoch, uint32_t f, unsigned long long t0) const {
     const double *A = FW + F.off;
     double *lds = ex.lds();
-    double *xs = lds, *tt = xs + F.Mp, *part = tt + F.Pp, *Db = part + (size_t)F.Pp * 4;  // Db: 16 x 16 diagonal block
+    double *xs = lds, *tt = xs + F.Mp, *part = tt + F.Pp, *Ul = part + (size_t)F.Pp * 4;
     const uint32_t *bnd = P.fr_bnd + F.bnd0;
+    const int lul = F.Mp + 1;  // (odd: a thread-per-row walk is bank-conflict free)
+    const bool res = (size_t)(Ul - lds) + (size_t)F.p * (size_t)lul <= (size_t)R.front_lds_doubles;
+    const double *U = res ? Ul : A;  // where the block loop reads the U rows
+    const int lu = res ? lul : F.ld;
     ex.wg_phase([&](int t) {
       SPICEY_NOUNROLL
       for (int i = t; i < F.Pp; i += T) tt[i] = i < F.p ? A[(size_t)i * F.ld + F.Mp] : 0.0;
-      load_db(F, A, Db, t, F.Pp - SPICEY_FB);
+      if (res) {
+        const int nw = T >> 6, w = t >> 6, lane = t & 63;
+        for (int i = w; i < F.p; i += nw) {
+          const double *src = A + (size_t)i * F.ld;
+          double *dst = Ul + (size_t)i * lul;
+          for (int c0 = (i & ~15) + lane; c0 < F.Mp; c0 += 64) dst[c0] = src[c0];  // (from the row's diagonal block on)
+        }
+      }
     });
     if (wait_parent) ex.front_wait(fl + P.nFronts + F.parent, epoch);
     stamp(f, 2, t0);
     ex.mark(SPICEY_PH_U0 + 10);
-    ex.wg_phase([&](int t) {  // t = y_P - U_PB x_B: four partial sums per row, combined in a fixed order
-      SPICEY_NOUNROLL
-      for (int it = t; it < F.p * 4; it += T) {
-        const int i = it >> 2, sg = it & 3;
-        const double *row = A + (size_t)i * F.ld + F.Pp;
-        const double *xW = W + (size_t)P.nLU;
-        double s = 0.0;
-        int j = sg;
-        for (; j + 12 < F.q; j += 16) {  // four (index -> unknown) chains and four matrix loads in flight; the sum keeps its order
-          const uint32_t b0 = bnd[j], b1 = bnd[j + 4], b2 = bnd[j + 8], b3 = bnd[j + 12];
-          const double r0 = row[j], r1 = row[j + 4], r2 = row[j + 8], r3 = row[j + 12];
-          const double x0 = xW[b0], x1 = xW[b1], x2 = xW[b2], x3 = xW[b3];
-          s = fma(r0, x0, s); s = fma(r1, x1, s); s = fma(r2, x2, s); s = fma(r3, x3, s);
+    if (F.q > 0) {
+      ex.wg_phase([&](int t) {  // t = y_P - U_PB x_B: four partial sums per row, combined in a fixed order
+        SPICEY_NOUNROLL
+        for (int it = t; it < F.p * 4; it += T) {
+          const int i = it >> 2, sg = it & 3;
+          const double *row = U + (size_t)i * lu + F.Pp;
+          const double *xW = W + (size_t)P.nLU;
+          double s = 0.0;
+          int j = sg;
+          for (; j + 12 < F.q; j += 16) {  // four (index -> unknown) chains and four matrix loads in flight; the sum keeps its order
+            const uint32_t b0 = bnd[j], b1 = bnd[j + 4], b2 = bnd[j + 8], b3 = bnd[j + 12];
+            const double r0 = row[j], r1 = row[j + 4], r2 = row[j + 8], r3 = row[j + 12];
+            const double x0 = xW[b0], x1 = xW[b1], x2 = xW[b2], x3 = xW[b3];
+            s = fma(r0, x0, s); s = fma(r1, x1, s); s = fma(r2, x2, s); s = fma(r3, x3, s);
+          }
+          for (; j < F.q; j += 4) s = fma(row[j], xW[bnd[j]], s);
+          part[it] = s;
         }
-        for (; j < F.q; j += 4) s = fma(row[j], xW[bnd[j]], s);
-        part[it] = s;
-      }
-    });
-    const int b_last = F.Pp - SPICEY_FB;
-    ex.wg_phase([&](int t) {
-      SPICEY_NOUNROLL
-      for (int i = t; i < F.p; i += T) tt[i] -= (part[4 * i] + part[4 * i + 1]) + (part[4 * i + 2] + part[4 * i + 3]);
-    });
-    for (int b0 = b_last; b0 >= 0; b0 -= SPICEY_FB) {
-      // one wave, 16 lanes in lockstep: step s solves x of row k = 15 - s and removes it from the rows above it
-      ex.wave_lockstep(SPICEY_FB, SPICEY_FB, [&](int lane, int s) {
-        const int k = SPICEY_FB - 1 - s;
-        if (lane > k) return;
-        const double x = tt[b0 + k] * Db[k * SPICEY_FB + k];
-        if (lane == k) xs[b0 + k] = x;
-        else tt[b0 + lane] = fma(-Db[lane * SPICEY_FB + k], x, tt[b0 + lane]);
       });
+      ex.wg_phase([&](int t) {
+        SPICEY_NOUNROLL
+        for (int i = t; i < F.p; i += T) tt[i] -= (part[4 * i] + part[4 * i + 1]) + (part[4 * i + 2] + part[4 * i + 3]);
+      });
+    }
+    for (int b0 = F.Pp - SPICEY_FB; b0 >= 0; b0 -= SPICEY_FB) {
+      solve16(U + (size_t)b0 * lu + b0, lu, b0, F.p, tt, xs);
       if (b0 == 0) break;
-      ex.wg_phase([&](int t) {  // rows above the block lose its 16 solved unknowns; next diagonal block -> LDS
+      ex.wg_phase([&](int t) {  // rows above the block lose its 16 solved unknowns
         SPICEY_NOUNROLL
         for (int i = t; i < b0 && i < F.p; i += T) {
-          const double *row = A + (size_t)i * F.ld + b0;
+          const double *row = U + (size_t)i * lu + b0;
+          double rk[SPICEY_FB];
+          SPICEY_UNROLL
+          for (int k = 0; k < SPICEY_FB; k++) rk[k] = row[k];
           double s = tt[i];
-          for (int k = 0; k < SPICEY_FB; k++) s = fma(-row[k], xs[b0 + k], s);
+          SPICEY_UNROLL
+          for (int k = 0; k < SPICEY_FB; k++) s = fma(-rk[k], xs[b0 + k], s);
           tt[i] = s;
         }
-        load_db(F, A, Db, t, b0 - SPICEY_FB);  // (the lockstep that read Db has ended with a workgroup barrier)
       });
     }
     ex.wg_phase([&](int t) {

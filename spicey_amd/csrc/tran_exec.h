@@ -69,6 +69,28 @@ static __device__ __forceinline__ double spicey_wave_max(double x) {
 }
 #define SPICEY_WAVE_MAX(x) spicey_wave_max(x)
 #define SPICEY_WAVE_LEADER(tid) (((tid) & 63) == 0)
+// cross-lane moves that do not go through the LDS crossbar (used on dependent chains of the dense fronts):
+// the value of ONE lane to all (wave-uniform: two v_readlane into scalars) ...
+static __device__ __forceinline__ double spicey_readlane_f64(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  asm volatile("" : "+v"(lo), "+v"(hi));  // back into vector registers at once: the kernels that use this have no scalar registers to spare
+  return __hiloint2double(hi, lo);
+}
+// ... and the value of lane q of every quad (4 consecutive lanes) to the quad (DPP quad_perm: a VALU move)
+template <int Q>
+static __device__ __forceinline__ double spicey_quad_bcast_q(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), Q * 0x55, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), Q * 0x55, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ double spicey_quad_bcast_f64(double v, int q) {
+  switch (q & 3) {
+    case 0: return spicey_quad_bcast_q<0>(v);
+    case 1: return spicey_quad_bcast_q<1>(v);
+    case 2: return spicey_quad_bcast_q<2>(v);
+    default: return spicey_quad_bcast_q<3>(v);
+  }
+}
 #define SPICEY_NOUNROLL _Pragma("unroll 1")  // thread-strided loops run 1-2 trips: unrolling only costs VGPRs
 #define SPICEY_UNROLL _Pragma("unroll")      // small fixed-trip loops over a register array: without it the array is indexed through s_set_gpr_idx
 #define SPICEY_SCHED_FENCE __builtin_amdgcn_sched_barrier(0)  // keep the K instances' code from being interleaved
