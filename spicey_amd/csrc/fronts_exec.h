@@ -209,6 +209,35 @@ struct FrontsRun {
   }
 
   // ---- triangular solves of a panel: one thread per row of the L panel, one per column of the U panel (rhs included) ----
+  // Both kinds run the same right-looking recurrence on 16 values: v_k (x 1 / u_kk for an L row), then v_j -= v_k op(k, j)
+  // for j > k — per entry the same operations in the same order as a left-looking dot product, with a dependent chain of 16
+  // steps instead of 120.  The operands (a row of the U block / a column of the multipliers: the same LDS words for every
+  // thread) are walked in 24 chunks of at most 8 — columns 1..7 of rows 0..7, then columns 8..15 of rows 0..7, then the
+  // lower right triangle — and chunk n + 1 is fetched while chunk n is used: left to itself the compiler waits for every LDS
+  // read right in front of the one or two operations that use it (60 exposed round trips per row; 16 with whole rows fetched
+  // step by step), and two whole rows in flight cost 60 registers where this costs 32.
+  template <bool LROW, class OP>
+  SPICEY_HD void trsm16(double *v, const double *Dinv, OP op) const {
+    double buf[2][8], dk[2];
+    // chunk n: n < 8: (k = n, j in [n + 1, 8));  n < 16: (k = n - 8, j in [8, 16));  else (k = n - 8, j in [n - 7, 16))
+    auto fetch = [&](int n) {
+      const int k = n < 8 ? n : n - 8, j0 = n < 8 ? n + 1 : (n < 16 ? 8 : n - 7), j1 = n < 8 ? 8 : 16;
+      SPICEY_UNROLL
+      for (int j = j0; j < j1; j++) buf[n & 1][j & 7] = op(k, j);
+      if (LROW && (n < 8 || n >= 16)) dk[n & 1] = Dinv[k];
+    };
+    fetch(0);
+    SPICEY_UNROLL
+    for (int n = 0; n < 24; n++) {
+      if (n + 1 < 24) fetch(n + 1);
+      SPICEY_SCHED_FENCE;
+      const int k = n < 8 ? n : n - 8, j0 = n < 8 ? n + 1 : (n < 16 ? 8 : n - 7), j1 = n < 8 ? 8 : 16;
+      if (LROW && (n < 8 || n >= 16)) v[k] *= dk[n & 1];
+      SPICEY_UNROLL
+      for (int j = j0; j < j1; j++) v[j] = fma(-v[k], buf[n & 1][j & 7], v[j]);
+      SPICEY_SCHED_FENCE;
+    }
+  }
   SPICEY_HD void panel_trsm(double *Up, int su, double *Lp, int lpld, const double *Ld, const double *Dinv, int nL, int nU, int t) const {
     // (the U columns start on a wave boundary behind the L rows: a wave that held both kinds ran both branches one after
     // the other and was the phase's critical path)
@@ -221,38 +250,14 @@ struct FrontsRun {
         double *row = Lp + (size_t)it * lpld;
         SPICEY_UNROLL
         for (int k = 0; k < SPICEY_FB; k++) v[k] = row[k];
-        // right-looking: l_k = v_k / u_kk, then the 15 - k later entries lose l_k u_kj — independent of each other, so the
-        // dependent chain is 16 steps instead of the 120 of a left-looking dot product per entry (same operations, same order per entry)
-        // (row k of the U block is fetched as a group before its multiply-adds: left to itself the compiler waits for every
-        // LDS read right in front of the one or two operations that use it — 60 exposed round trips per row instead of 16)
-        SPICEY_UNROLL
-        for (int k = 0; k < SPICEY_FB; k++) {
-          double uk[SPICEY_FB];
-          SPICEY_UNROLL
-          for (int j = k + 1; j < SPICEY_FB; j++) uk[j] = Up[(size_t)k * su + j];
-          const double dk = Dinv[k];
-          SPICEY_SCHED_FENCE;
-          v[k] *= dk;
-          SPICEY_UNROLL
-          for (int j = k + 1; j < SPICEY_FB; j++) v[j] = fma(-v[k], uk[j], v[j]);
-          SPICEY_SCHED_FENCE;
-        }
+        trsm16<true>(v, Dinv, [&](int k, int j) { return Up[(size_t)k * su + j]; });
         SPICEY_UNROLL
         for (int k = 0; k < SPICEY_FB; k++) row[k] = v[k];
       } else {
         const int c = SPICEY_FB + (it - nL64);
         SPICEY_UNROLL
         for (int k = 0; k < SPICEY_FB; k++) v[k] = Up[(size_t)k * su + c];
-        SPICEY_UNROLL
-        for (int k = 0; k < SPICEY_FB - 1; k++) {
-          double lk[SPICEY_FB];
-          SPICEY_UNROLL
-          for (int i2 = k + 1; i2 < SPICEY_FB; i2++) lk[i2] = Ld[i2 * SPICEY_FB + k];
-          SPICEY_SCHED_FENCE;
-          SPICEY_UNROLL
-          for (int i2 = k + 1; i2 < SPICEY_FB; i2++) v[i2] = fma(-lk[i2], v[k], v[i2]);
-          SPICEY_SCHED_FENCE;
-        }
+        trsm16<false>(v, Dinv, [&](int k, int j) { return Ld[j * SPICEY_FB + k]; });
         SPICEY_UNROLL
         for (int k = 1; k < SPICEY_FB; k++) Up[(size_t)k * su + c] = v[k];
       }
@@ -327,14 +332,15 @@ struct FrontsRun {
   // panel being formed) or in the workspace (the contribution block).  Same products in the same order per entry as the
   // right-looking sweep (panel after panel, k ascending, the same MFMA tiling): bit-identical to it.
   SPICEY_HD static int loff(int pj, int Mp) { return SPICEY_LPLD * pj * (Mp - SPICEY_FB - (SPICEY_FB / 2) * (pj - 1)); }
-  template <int NT = 2>
+  template <int CH = 4>
   SPICEY_HD void trailing_left(double *C, int ldc, int nrow, int ncol, int npan, const double *Lall, int Mp, int grow0, const double *A, int ld, int gcol0,
                                int t) const {
     const int nw = T >> 6, w = t >> 6, lane = t & 63;
 #if defined(__HIP_DEVICE_COMPILE__)
-    // (instruction economy as in trailing(): scalar tile walk, lane parts of the addresses formed once.)  The operands of
-    // panel pj + 1 are fetched before the MFMAs of panel pj are issued (two register sets, used alternately): the U rows come
-    // from the workspace (L2), and one exposed round trip per panel and turn was most of this update's time.
+    // (instruction economy as in trailing(): scalar tile walk, lane parts of the addresses formed once.)  The U rows come
+    // from the workspace (L2, ~1 us per round trip) and the MFMAs of a tile are nothing beside that, so what counts is round
+    // trips: one tile per turn, the operands of CH panels fetched together — ceil(npan / CH) round trips per tile (one per
+    // panel, as first written, was most of a staged front's time).
     typedef double d4 __attribute__((ext_vector_type(4)));
     const int ws = SPICEY_UNIFORM(w);
     const int tr = nrow >> 4, tc = (ncol + 15) >> 4;
@@ -345,53 +351,108 @@ struct FrontsRun {
     const int dti = nw / tc, dtj = nw - dti * tc;
     int ti = ws / tc, tj = ws - ti * tc;
     while (ti < tr) {
-      double *c0[NT];
-      const double *la[NT], *ub[NT];
-      d4 acc[NT], av[2][NT], bv[2][NT];
-      bool have[NT];
-      SPICEY_UNROLL
-      for (int b = 0; b < NT; b++) {
-        have[b] = ti < tr;
-        const int ui = have[b] ? ti : 0, uj = have[b] ? tj : 0;
-        c0[b] = cl + ((size_t)ui * 16 * ldc + (size_t)uj * 16);
-        la[b] = al + (size_t)ui * 16 * SPICEY_LPLD;
-        ub[b] = bl + (size_t)uj * 16;
-        acc[b][0] = c0[b][0]; acc[b][1] = c0[b][(size_t)4 * ldc]; acc[b][2] = c0[b][(size_t)8 * ldc]; acc[b][3] = c0[b][(size_t)12 * ldc];
-        tj += dtj; ti += dti;
-        if (tj >= tc) { tj -= tc; ti++; }
-      }
-      auto fetch = [&](int set, int lo) {  // lo = loff(pj) - 16 pj LPLD
-        SPICEY_UNROLL
-        for (int b = 0; b < NT; b++) {
-          const double *x = la[b] + lo;
-          av[set][b][0] = x[0]; av[set][b][1] = x[4]; av[set][b][2] = x[8]; av[set][b][3] = x[12];
-          bv[set][b][0] = ub[b][0]; bv[set][b][1] = ub[b][(size_t)4 * ld]; bv[set][b][2] = ub[b][(size_t)8 * ld]; bv[set][b][3] = ub[b][(size_t)12 * ld];
-          ub[b] += (size_t)SPICEY_FB * ld;
-        }
-      };
-      auto mult = [&](int set) {
-        SPICEY_UNROLL
-        for (int b = 0; b < NT; b++) {
-          SPICEY_UNROLL
-          for (int kk = 0; kk < 4; kk++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[set][b][kk], bv[set][b][kk], acc[b], 0, 0, 0);
-        }
-      };
+      double *c0 = cl + ((size_t)ti * 16 * ldc + (size_t)tj * 16);
+      const double *la = al + (size_t)ti * 16 * SPICEY_LPLD;
+      const double *ub = bl + (size_t)tj * 16;
+      d4 acc;
+      acc[0] = c0[0]; acc[1] = c0[(size_t)4 * ldc]; acc[2] = c0[(size_t)8 * ldc]; acc[3] = c0[(size_t)12 * ldc];
       int lo = 0;  // loff(pj, Mp) - 16 pj LPLD, advanced by LPLD (Mp - 32 - 16 pj) per panel
-      if (npan > 0) fetch(0, lo);
-      for (int pj = 0; pj < npan; pj += 2) {
-        lo += SPICEY_LPLD * (Mp - 2 * SPICEY_FB - SPICEY_FB * pj);
-        if (pj + 1 < npan) fetch(1, lo);
+      for (int p0 = 0; p0 < npan; p0 += CH) {
+        d4 av[CH], bv[CH];
+        SPICEY_UNROLL
+        for (int c = 0; c < CH; c++) {
+          const bool on = p0 + c < npan;  // (wave-uniform; an absent panel repeats the last one and is not multiplied)
+          const double *x = la + lo;
+          av[c][0] = x[0]; av[c][1] = x[4]; av[c][2] = x[8]; av[c][3] = x[12];
+          bv[c][0] = ub[0]; bv[c][1] = ub[(size_t)4 * ld]; bv[c][2] = ub[(size_t)8 * ld]; bv[c][3] = ub[(size_t)12 * ld];
+          if (p0 + c + 1 < npan) { lo += SPICEY_LPLD * (Mp - 2 * SPICEY_FB - SPICEY_FB * (p0 + c)); ub += (size_t)SPICEY_FB * ld; }
+          (void)on;
+        }
         SPICEY_SCHED_FENCE;
-        mult(0);
-        if (pj + 1 >= npan) break;
-        lo += SPICEY_LPLD * (Mp - 2 * SPICEY_FB - SPICEY_FB * (pj + 1));
-        if (pj + 2 < npan) fetch(0, lo);
-        SPICEY_SCHED_FENCE;
-        mult(1);
+        SPICEY_UNROLL
+        for (int c = 0; c < CH; c++) {
+          if (p0 + c < npan) {
+            SPICEY_UNROLL
+            for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[c][kk], bv[c][kk], acc, 0, 0, 0);
+          }
+        }
       }
-      SPICEY_UNROLL
-      for (int b = 0; b < NT; b++)
-        if (have[b]) { c0[b][0] = acc[b][0]; c0[b][(size_t)4 * ldc] = acc[b][1]; c0[b][(size_t)8 * ldc] = acc[b][2]; c0[b][(size_t)12 * ldc] = acc[b][3]; }
+      c0[0] = acc[0]; c0[(size_t)4 * ldc] = acc[1]; c0[(size_t)8 * ldc] = acc[2]; c0[(size_t)12 * ldc] = acc[3];
+      tj += dtj; ti += dti;
+      if (tj >= tc) { tj -= tc; ti++; }
+    }
+#else
+    const int nchunk = (ncol + 63) >> 6;
+    for (int pr = w; pr < nrow * nchunk; pr += nw) {
+      const int i = pr / nchunk, j = (pr - i * nchunk) * 64 + lane;
+      if (j >= ncol) continue;
+      double acc = C[(size_t)i * ldc + j];
+      for (int pj = 0; pj < npan; pj++) {
+        const double *l = Lall + loff(pj, Mp) + (size_t)(grow0 + i - SPICEY_FB * pj - SPICEY_FB) * SPICEY_LPLD;
+        for (int k = 0; k < SPICEY_FB; k++) acc = fma(-l[k], A[(size_t)(SPICEY_FB * pj + k) * ld + gcol0 + j], acc);
+      }
+      C[(size_t)i * ldc + j] = acc;
+    }
+#endif
+  }
+  // the same update with a wave per tile COLUMN (for fronts with more panels than one fetch of the tile walk holds)
+  template <int CH = 5>
+  SPICEY_HD void trailing_left_cols(double *C, int ldc, int nrow, int ncol, int npan, const double *Lall, int Mp, int grow0, const double *A, int ld, int gcol0,
+                               int t) const {
+    const int nw = T >> 6, w = t >> 6, lane = t & 63;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Instruction economy as in trailing(): wave-uniform walk in scalar registers, lane parts of the addresses formed once.
+    // The U rows come from the workspace (L2, ~1 us per round trip) and the MFMAs of a tile are nothing beside that, so the
+    // walk is built around round trips: a wave owns a COLUMN of tiles — the U operands of that column (CH panels at a time;
+    // every staged front of the 100 x 100 mesh has at most 5) are fetched once and serve all its row tiles — and the C tile of
+    // the next row is fetched while the current one is multiplied.  With fewer tile columns than waves the rows of a column
+    // are dealt out to nw / tc waves.  (Tile by tile, one fetch per panel: 7 x 5 round trips per wave on the contribution
+    // block of the (71, 100) front; now 2 + 7 overlapped.)
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int ws = SPICEY_UNIFORM(w);
+    const int tr = nrow >> 4, tc = (ncol + 15) >> 4;
+    const int li = lane & 15, lk = lane >> 4;
+    const int share = tc < nw ? nw / tc : 1;           // waves per tile column
+    const int col0 = tc < nw ? ws % tc : ws, cstep = tc < nw ? tc : nw;
+    const int row0 = tc < nw ? ws / tc : 0;            // (waves beyond share * tc: row0 >= share, they get no rows)
+    if (row0 >= share) return;
+    double *cl = C + (size_t)lk * ldc + li;
+    const double *al = Lall + (size_t)(grow0 + li - SPICEY_FB) * SPICEY_LPLD + lk;  // + 16 ti LPLD + [loff(pj) - 16 pj LPLD] + 4 kk
+    const double *bl = A + (size_t)lk * ld + gcol0 + li;                            // + 16 pj ld + 16 tj + 4 kk ld
+    for (int tj = col0; tj < tc; tj += cstep) {
+      int lo0 = 0;  // loff(p0, Mp) - 16 p0 LPLD
+      for (int p0 = 0; p0 < npan; p0 += CH) {
+        d4 bv[CH];
+        SPICEY_UNROLL
+        for (int c = 0; c < CH; c++) {
+          const double *y = bl + (size_t)tj * 16 + (size_t)(p0 + c < npan ? p0 + c : p0) * SPICEY_FB * ld;  // (an absent panel repeats the chunk's first; not multiplied)
+          bv[c][0] = y[0]; bv[c][1] = y[(size_t)4 * ld]; bv[c][2] = y[(size_t)8 * ld]; bv[c][3] = y[(size_t)12 * ld];
+        }
+        double *cp = cl + ((size_t)row0 * 16 * ldc + (size_t)tj * 16);
+        d4 cn;
+        if (row0 < tr) { cn[0] = cp[0]; cn[1] = cp[(size_t)4 * ldc]; cn[2] = cp[(size_t)8 * ldc]; cn[3] = cp[(size_t)12 * ldc]; }
+        for (int ti = row0; ti < tr; ti += share) {
+          d4 acc = cn;
+          double *c0 = cp;
+          cp += (size_t)share * 16 * ldc;
+          if (ti + share < tr) { cn[0] = cp[0]; cn[1] = cp[(size_t)4 * ldc]; cn[2] = cp[(size_t)8 * ldc]; cn[3] = cp[(size_t)12 * ldc]; }
+          const double *la = al + (size_t)ti * 16 * SPICEY_LPLD;
+          int lo = lo0;
+          SPICEY_UNROLL
+          for (int c = 0; c < CH; c++) {
+            if (p0 + c < npan) {
+              const double *x = la + lo;
+              d4 av;
+              av[0] = x[0]; av[1] = x[4]; av[2] = x[8]; av[3] = x[12];
+              SPICEY_UNROLL
+              for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[c][kk], acc, 0, 0, 0);
+              lo += SPICEY_LPLD * (Mp - 2 * SPICEY_FB - SPICEY_FB * (p0 + c));
+            }
+          }
+          c0[0] = acc[0]; c0[(size_t)4 * ldc] = acc[1]; c0[(size_t)8 * ldc] = acc[2]; c0[(size_t)12 * ldc] = acc[3];
+        }
+        for (int c = 0; c < CH && p0 + c < npan; c++) lo0 += SPICEY_LPLD * (Mp - 2 * SPICEY_FB - SPICEY_FB * (p0 + c));
+      }
     }
 #else
     const int nchunk = (ncol + 63) >> 6;
@@ -467,14 +528,38 @@ struct FrontsRun {
       double *Lp = Lall + loff(pj, Mp);
       ex.wg_phase([&](int t) {  // stage the panel: its 16 rows (from the diagonal block to the right-hand side), its column block below
         const int nw = T >> 6, w = t >> 6, lane = t & 63;
-        for (int k = w; k < SPICEY_FB; k += nw) {
-          const double *src = A + (size_t)(j0 + k) * ld + j0;
-          for (int c = lane; c < su; c += 64) Up[(size_t)k * su + c] = src[c];
+        // (all loads of a thread first, then its stores: one L2 round trip for the rows instead of one per 64 columns)
+        for (int k = w; k < SPICEY_FB; k += 2 * nw) {
+          const bool two = k + nw < SPICEY_FB;
+          const double *s0 = A + (size_t)(j0 + k) * ld + j0, *s1 = A + (size_t)(j0 + (two ? k + nw : k)) * ld + j0;
+          double *d0 = Up + (size_t)k * su, *d1 = Up + (size_t)(k + nw) * su;
+          for (int cb = 0; cb < su; cb += 256) {
+            double v0[4], v1[4];
+            SPICEY_UNROLL
+            for (int b = 0; b < 4; b++) {
+              const int c = cb + 64 * b + lane;
+              v0[b] = s0[c < su ? c : 0]; v1[b] = s1[c < su ? c : 0];
+            }
+            SPICEY_UNROLL
+            for (int b = 0; b < 4; b++) {
+              const int c = cb + 64 * b + lane;
+              if (c < su) { d0[c] = v0[b]; if (two) d1[c] = v1[b]; }
+            }
+          }
         }
+        // the column block below: 16 lanes per row, four rows of a thread in flight together (one L2 round trip per four)
+        const double *src = A + (size_t)(j0 + SPICEY_FB + (t >> 4)) * ld + j0 + (t & 15);
+        double *dst = Lp + (size_t)(t >> 4) * SPICEY_LPLD + (t & 15);
+        const size_t sstep = (size_t)(T >> 4) * ld, dstep = (size_t)(T >> 4) * SPICEY_LPLD;
         SPICEY_NOUNROLL
-        for (int i = t; i < nL * SPICEY_FB; i += T) {
-          const int r = i >> 4, k = i & 15;
-          Lp[(size_t)r * SPICEY_LPLD + k] = A[(size_t)(j0 + SPICEY_FB + r) * ld + j0 + k];
+        for (int r0 = t >> 4; r0 < nL; r0 += 4 * (T >> 4)) {
+          double v[4];
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++) v[b] = src[(r0 + b * (T >> 4) < nL ? b : 0) * sstep];
+          SPICEY_UNROLL
+          for (int b = 0; b < 4; b++)
+            if (r0 + b * (T >> 4) < nL) dst[b * dstep] = v[b];
+          src += 4 * sstep; dst += 4 * dstep;
         }
       });
       ex.mark(SPICEY_PH_U0 + 24);
@@ -495,14 +580,15 @@ struct FrontsRun {
           for (int c = lane; c < wU; c += 64) dst[c] = c == k ? Dinv[k] : Up[(size_t)k * su + c];
         }
       });
-      ex.mark(SPICEY_PH_U0 + 24);
+      ex.mark(SPICEY_PH_U0 + 28);
     }
     // contribution block (rows and columns of the boundary, right-hand side included): every panel's products in one pass
     if (Mp > F.Pp)
       ex.wg_phase([&](int t) {
-        trailing_left(A + (size_t)F.Pp * ld + F.Pp, ld, Mp - F.Pp, Mp + 1 - F.Pp, F.Pp / SPICEY_FB, Lall, Mp, F.Pp, A, ld, F.Pp, t);
+        if (F.Pp > 4 * SPICEY_FB) trailing_left_cols(A + (size_t)F.Pp * ld + F.Pp, ld, Mp - F.Pp, Mp + 1 - F.Pp, F.Pp / SPICEY_FB, Lall, Mp, F.Pp, A, ld, F.Pp, t);
+        else trailing_left(A + (size_t)F.Pp * ld + F.Pp, ld, Mp - F.Pp, Mp + 1 - F.Pp, F.Pp / SPICEY_FB, Lall, Mp, F.Pp, A, ld, F.Pp, t);
       });
-    ex.mark(SPICEY_PH_U0 + 27);
+    ex.mark(SPICEY_PH_U0 + 29);
   }
   SPICEY_HD void factor_global(const SpiceyFront &F) const {
     if (!R.front_right_looking && left_lds_need(F) <= SPICEY_FRONT_LDS_DOUBLES) { factor_global_left(F); return; }

@@ -5,5 +5,5 @@
 #define SPICEY_FRONT_LDS_DOUBLES 19456  // 152 KiB of LDS scratch per workgroup when a program has fronts
 #define SPICEY_FRONT_LDS_PAD 17  // an LDS-resident front has row stride Mp + 17 (odd; room for the right-hand-side tile)
 #ifndef SPICEY_TRAIL_TILES_STAGED
-#define SPICEY_TRAIL_TILES_STAGED 4  // 16 x 16 tiles a wave keeps in flight per turn of a trailing update whose C lives in the workspace (measured on rcd_mesh(100): 4 -> 0.481, 6 -> 0.486, 8 -> 0.495 ms per step)
+#define SPICEY_TRAIL_TILES_STAGED 2  // 16 x 16 tiles a wave keeps in flight per turn of the right-looking update of a staged front (the fallback path; all operands of a turn are loaded before its first MFMA: 24 registers per tile)
 #endif

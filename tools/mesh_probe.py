@@ -56,7 +56,7 @@ for rows in args.rows:
                      12: "f.wait", 13: "f.asm_children(lds)", 14: "f.factor_lds_rest", 15: "f.store", 16: "f.asm(glob)", 17: "f.factor(glob)",
                      18: "b.wait", 19: "b.solve", 20: "f.post", 21: "l.pre", 22: "l.diag", 23: "l.trsm", 24: "l.trail", 25: "a.zero+asm",
                      26: "bins.factor", 27: "bins.sync", 28: "bk.interface", 29: "bk.bins", 30: "factor.interface.work", 31: "bk.interface.work",
-                     32: "g.stage_in", 33: "g.diag", 34: "g.trsm", 35: "g.store+trail"}
+                     32: "g.stage_in", 33: "g.diag", 34: "g.trsm", 35: "g.update", 36: "g.store", 37: "g.cb"}
             for wgi in range(info["wgs_per_inst"]):
                 tk = h.section_ticks(wgi)
                 per = {names[k]: round(tk[k] * 10.0 / 1000.0 / (steps + 1), 1) for k in names}  # us per step
