@@ -14,7 +14,7 @@ size_t spicey_gw_doubles_per_wg(const SpiceyProg &P, int K);
 hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bool lds, int grid, int threads, hipStream_t st);
 
 // v2 (register-resident program): slots per thread for a workgroup size, and the launcher (K in {1, 2})
-int spicey_v2_rmax(int threads, bool packed = false);
+int spicey_v2_rmax(int threads, bool packed = false, bool hybrid = false);
 int spicey_v2_nsv(int threads, bool packed = false);
 int spicey_v2_nel(int threads, bool packed = false);
 int spicey_v2_max_threads(int K);

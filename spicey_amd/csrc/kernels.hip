@@ -663,7 +663,8 @@ hipError_t spicey_launch_tran(const SpiceyProg &P, const SpiceyRun &R, int K, bo
 // `packed` = the two-workgroups-per-CU geometry: 512 threads, <= 128 VGPRs; only 4 slots stay resident (the small,
 // latency-critical phases), the wide bottom levels are streamed from L2 with the records prefetched in batches.
 #define SPICEY_V2_RMAX256 28  // (32 slots spilled 6 vector registers to AGPRs: refused by check_no_spills.py)
-int spicey_v2_rmax(int threads, bool packed) { return packed ? 4 : (threads <= 256 ? SPICEY_V2_RMAX256 : (threads <= 512 ? 16 : 8)); }
+// (hybrid workspace at 1024 threads: 4 slots — with 8 the build spills 10 registers at the 128-register cap)
+int spicey_v2_rmax(int threads, bool packed, bool hybrid) { return packed ? 4 : (threads <= 256 ? SPICEY_V2_RMAX256 : (threads <= 512 ? 16 : (hybrid ? 4 : 8))); }
 int spicey_v2_nsv(int threads, bool packed) { return packed ? 6 : (threads <= 256 ? 12 : (threads <= 512 ? 8 : 4)); }
 int spicey_v2_nel(int threads, bool packed) { return packed ? 2 : (threads <= 256 ? 4 : (threads <= 512 ? 2 : 1)); }
 int spicey_v2_max_threads(int K) { return K == 1 ? 1024 : 0; }
@@ -676,10 +677,10 @@ hipError_t spicey_launch_tran_v2(const SpiceyProg &Ph, const SpiceyResident &Qh,
     return hipErrorInvalidValue;
   }
   if (Ph.hybrid) {
-    // hybrid workspace: built for 512 threads (16 slots, 8 entries, 2 elements per thread: the resident capacity of the
-    // 1024-thread geometry at half the threads; the 1024-thread build of this variant spilled 8 vector registers at its
-    // 128-register cap, which the build refuses)
+    // hybrid workspace: 1024 threads (4 slots, 4 entries, 1 element per thread, loads of the beyond-resident loops two at a
+    // time: what fits 128 registers) or 512 threads (16 slots, 8 entries, 2 elements, four at a time)
     if (K == 1 && threads == 512) return launch_v2_t<1, 16, 8, 2, 512, 2, true>(P, Q, R, grid, threads, bytes, st);
+    if (K == 1 && threads == 1024) return launch_v2_t<1, 4, 4, 1, 1024, 4, true>(P, Q, R, grid, threads, bytes, st);
     return hipErrorInvalidValue;
   }
   if (threads <= 256) {

@@ -307,9 +307,10 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   // elimination tree does keeps the 16-bit register-resident interpreter — the entries the LEAVES own (half of L+U under
   // nested dissection) and the element vectors move to global memory, read by one factor phase and one backward phase.
   // Without it such a circuit falls to the 32-bit task lists on a global workspace (diode_chain(2600): 56 us per step on 16
-  // cooperating workgroups against ~16 for the 2000-node chain that still fits).  One instance per workgroup, 512 threads.
+  // cooperating workgroups against ~16 for the 2000-node chain that still fits).  One instance per workgroup; 1024 threads
+  // (SpiceyOptions.threads = 512 selects the 512-thread build of the same kernel).
   if (want_lds && (h->opt.inst_per_wg == 0 || h->opt.inst_per_wg == 1) && h->opt.interpreter != 1 && h->opt.geometry != 2 && P.has16 && P.nFronts == 0 &&
-      (h->opt.threads == 0 || h->opt.threads == 512) && h->opt.wgs_per_inst <= 1 && !diag && !getenv("SPICEY_NO_HYBRID") &&
+      (h->opt.threads == 0 || h->opt.threads == 512 || h->opt.threads == 1024) && h->opt.wgs_per_inst <= 1 && !diag && !getenv("SPICEY_NO_HYBRID") &&
       spicey_lds_bytes(P, 1, true, 5) > SPICEY_LDS_MAX) {
     HostProgram hyb;
     std::string err2;
@@ -333,7 +334,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
   h->T = h->opt.threads > 0 ? h->opt.threads : pick_threads(h->hp, h->interp == 2, K);
   if (P.hybrid) {
     if (h->interp != 2) { h->err = "internal: hybrid layout without the 16-bit interpreter"; return fail(SPICEY_ERR_BAD_DESC); }
-    h->T = 512;  // (the geometry the hybrid kernel is built for: kernels.hip, spicey_launch_tran_v2)
+    h->T = h->opt.threads == 512 ? 512 : 1024;  // (the two geometries the hybrid kernel is built for: kernels.hip, spicey_launch_tran_v2)
   }
   if (P.nFronts > 0 && h->T > 512) {  // kernels with the dense-front code are built for <= 512 threads (256 VGPRs)
     if (h->opt.threads > 512) { h->err = "front_cut needs threads <= 512"; return fail(SPICEY_ERR_BAD_DESC); }
@@ -358,7 +359,7 @@ extern "C" int32_t spicey_create(const SpiceyDesc *desc, const SpiceyOptions *op
     const size_t lds_cap = h->packed ? SPICEY_LDS_MAX / 2 : SPICEY_LDS_MAX;
     int max_tail = (int)std::min<size_t>(24, base < lds_cap ? (lds_cap - base) / 1024 : 0);
     if (h->opt.debug & 1) max_tail = 0;  // diagnostics: disable the tail merge
-    spicey_build_resident(h->hp, h->T, spicey_v2_rmax(h->T, h->packed), h->hres, max_tail, !((h->opt.debug >> 6) & 1));  // diagnostics: bit 6 = no row records
+    spicey_build_resident(h->hp, h->T, spicey_v2_rmax(h->T, h->packed, P.hybrid != 0), h->hres, max_tail, !((h->opt.debug >> 6) & 1));  // diagnostics: bit 6 = no row records
     h->lds_bytes = spicey_lds_bytes(P, K, true, h->hres.tail_n);
   }
 

@@ -609,7 +609,8 @@ struct TranPhases {
 #if defined(__clang__)
 template <int N> struct U32Vec { typedef uint32_t type __attribute__((ext_vector_type(N))); };
 #else
-template <int N> struct U32Vec { typedef uint32_t type __attribute__((vector_size(N * 4))); };
+template <int N> struct U32Arr { uint32_t v[N]; uint32_t &operator[](int i) { return v[i]; } const uint32_t &operator[](int i) const { return v[i]; } };
+template <int N> struct U32Vec { typedef U32Arr<N> type; };  // (host build: a plain array; gcc's vector types want a power of two)
 #endif
 
 template <int K, int RMAX, int NSV, int NEL>
@@ -617,7 +618,7 @@ struct ResRegs {
   // factor / backward task records, one 16-byte record per slot, word-major; the slots of a wave are sorted
   // by phase, `phv` holds the phase id of every slot (one byte each, 0xFF = unused), `cursor` the next slot
   typename U32Vec<RMAX>::type w0, w1, w2, w3;
-  typename U32Vec<RMAX / 4>::type phv;
+  typename U32Vec<(RMAX + 3) / 4>::type phv;
   int32_t cursor;
   // entries with dynamic stamps are numbered first: only the first NDD slots can hold one and need a descriptor
   static constexpr int NDD = NSV == 6 ? 2 : NSV / 2;
@@ -868,9 +869,10 @@ SPICEY_HD void spicey_uk_phase(const SpiceyProg &P, const SpiceyResident &Q, con
     // generic records of rows that do not fit the pattern
     const uint32_t npair = d_cnt;
     const uint32_t *pb = P.fus16 + (size_t)d_first * 4;
-    if constexpr (OPG) {
+    if constexpr (OPG && NEL >= 2) {
       // (hybrid workspace: the leaves' own entries come from L2 — two row records at a time, both fetched before either is
-      // executed, so that the operand loads of the second are in flight under the first)
+      // executed, so that the operand loads of the second are in flight under the first; the 1024-thread build — NEL = 1 —
+      // has half the records per thread and no registers for a second one)
       SPICEY_NOUNROLL
       for (uint32_t j = (uint32_t)tid; j < npair; j += 2u * (uint32_t)T) {
         const uint32_t j2 = j + (uint32_t)T;
@@ -944,6 +946,9 @@ struct TranPhases2 {
   // 128 VGPRs and nothing to spare — with them that kernel spills, which the build refuses); the host keeps a handle with
   // the option out of that geometry
   static constexpr bool DIAG = NSV != 6 && !HYB;  // (nor into the hybrid-workspace build, for the same reason)
+  // hybrid builds: items of a beyond-resident loop whose loads are in flight together (the 1024-thread build has 128 registers)
+  static constexpr int BW = NEL >= 2 ? 4 : 2;   // (phase Z)
+  static constexpr int BWB = BW;                 // (phase B; four at a time in the 1024-thread build compiled — 126 registers — and was 5 % slower per step)
   SPICEY_HD void set_remainders() {
     brem = (P.nRestore > NSV * T ? 1u : 0u) | (P.nDynX > 0 ? 2u : 0u) | (P.n > NEL * T ? 4u : 0u) | (P.nRowX > 0 ? 8u : 0u) |
            (P.nDynEnt > Regs::NDD * T ? 16u : 0u);
@@ -967,11 +972,11 @@ struct TranPhases2 {
       const uint32_t *src = Q.res + ((size_t)(have ? s : 0) * T + tid) * 4;
       rr.w0[s] = have ? src[0] : 0u; rr.w1[s] = have ? src[1] : 0u; rr.w2[s] = have ? src[2] : 0u; rr.w3[s] = have ? src[3] : 0u;
     }
-    for (int s4 = 0; s4 < RMAX / 4; s4++) {
+    for (int s4 = 0; s4 < (RMAX + 3) / 4; s4++) {
       uint32_t pk = 0;
       for (int b = 0; b < 4; b++) {
         const int s = s4 * 4 + b;
-        const int ph = s < Q.rmax ? Q.res_phase[(size_t)(tid >> 6) * Q.rmax + s] : -1;
+        const int ph = s < Q.rmax && s < RMAX ? Q.res_phase[(size_t)(tid >> 6) * Q.rmax + s] : -1;
         pk |= (uint32_t)(ph < 0 ? 0xff : (ph & 0xff)) << (8 * b);
       }
       rr.phv[s4] = SPICEY_UNIFORM((int)pk);
@@ -1086,25 +1091,25 @@ struct TranPhases2 {
     // dynamic entries beyond the descriptor slots: [NDD T, nDynEnt)
     if (brem & 16u)
     SPICEY_NOUNROLL
-    for (int e0 = tid + Regs::NDD * T; e0 < P.nDynEnt; e0 += 4 * T) {
-      uint32_t dd[4];
-      double v[4], ga[4], gb[4];
+    for (int e0 = tid + Regs::NDD * T; e0 < P.nDynEnt; e0 += BWB * T) {
+      uint32_t dd[BWB];
+      double v[BWB], ga[BWB], gb[BWB];
       SPICEY_UNROLL
-      for (int b = 0; b < 4; b++) {
+      for (int b = 0; b < BWB; b++) {
         const int e = e0 + b * T;
         const bool have = e < P.nDynEnt;
         dd[b] = have ? P.ent_dd[e] : 0x80000000u;
         v[b] = sv0[have ? e : e0];
       }
       SPICEY_UNROLL
-      for (int b = 0; b < 4; b++) {
+      for (int b = 0; b < BWB; b++) {
         const uint32_t f0 = dd[b] & 0x7fffu, f1 = (dd[b] >> 15) & 0x7fffu;
         const bool on = !(dd[b] >> 31);
         ga[b] = c.gd[(on && f0) ? (f0 & 0x3fffu) - 1 : 0u];
         gb[b] = c.gd[(on && f1) ? (f1 & 0x3fffu) - 1 : 0u];
       }
       SPICEY_UNROLL
-      for (int b = 0; b < 4; b++) {
+      for (int b = 0; b < BWB; b++) {
         if (dd[b] >> 31) continue;
         const uint32_t f0 = dd[b] & 0x7fffu, f1 = (dd[b] >> 15) & 0x7fffu;
         double x = v[b];
@@ -1122,12 +1127,12 @@ struct TranPhases2 {
       int e0 = tid + NSV * T;
       if (e0 < P.nDynEnt) e0 += ((P.nDynEnt - e0 + T - 1) / T) * T;
       SPICEY_NOUNROLL
-      for (; e0 < P.nRestore; e0 += 4 * T) {
-        double v[4];
+      for (; e0 < P.nRestore; e0 += BWB * T) {
+        double v[BWB];
         SPICEY_UNROLL
-        for (int b = 0; b < 4; b++) v[b] = sv0[e0 + b * T < P.nRestore ? e0 + b * T : e0];
+        for (int b = 0; b < BWB; b++) v[b] = sv0[e0 + b * T < P.nRestore ? e0 + b * T : e0];
         SPICEY_UNROLL
-        for (int b = 0; b < 4; b++)
+        for (int b = 0; b < BWB; b++)
           if (e0 + b * T < P.nRestore) put_entry((uint32_t)(e0 + b * T), 0, v[b]);
       }
     }
@@ -1151,24 +1156,24 @@ struct TranPhases2 {
   // right-hand-side rows beyond the resident ones, four at a time: descriptors, then all their (up to 16) contributions
   SPICEY_HD void rhs_rest_batched(int tid) const {
     SPICEY_NOUNROLL
-    for (int r0 = tid + NEL * T; r0 < P.n; r0 += 4 * T) {
-      uint32_t d[4][2];
-      double t[4][4];
+    for (int r0 = tid + NEL * T; r0 < P.n; r0 += BWB * T) {
+      uint32_t d[BWB][2];
+      double t[BWB][4];
       SPICEY_UNROLL
-      for (int b = 0; b < 4; b++) {
+      for (int b = 0; b < BWB; b++) {
         const int r = r0 + b * T < P.n ? r0 + b * T : r0;
         d[b][0] = P.row_desc[(size_t)r * 2]; d[b][1] = P.row_desc[(size_t)r * 2 + 1];
         if (r0 + b * T >= P.n) d[b][1] = 0xFFFFFFFFu;
       }
       SPICEY_UNROLL
-      for (int b = 0; b < 4; b++) {
+      for (int b = 0; b < BWB; b++) {
         const bool on = d[b][1] != 0xFFFFFFFFu;
         const uint32_t f[4] = {d[b][0] & 0xffffu, d[b][0] >> 16, d[b][1] & 0xffffu, d[b][1] >> 16};
         SPICEY_UNROLL
         for (int i = 0; i < 4; i++) t[b][i] = c.u[(on && f[i]) ? (f[i] & 0x7fffu) - 1 : 0u];
       }
       SPICEY_UNROLL
-      for (int b = 0; b < 4; b++) {
+      for (int b = 0; b < BWB; b++) {
         if (d[b][1] == 0xFFFFFFFFu) continue;
         const uint32_t f[4] = {d[b][0] & 0xffffu, d[b][0] >> 16, d[b][1] & 0xffffu, d[b][1] >> 16};
         double acc = 0.0;
@@ -1487,44 +1492,44 @@ struct TranPhases2 {
         // first terminal voltage is read; the same arithmetic per item as the loops below)
         if (zrem & 1u)
         SPICEY_NOUNROLL
-        for (int i0 = tid + NEL * T; i0 < P.nOut; i0 += 4 * T) {
-          int32_t xi[4];
+        for (int i0 = tid + NEL * T; i0 < P.nOut; i0 += BW * T) {
+          int32_t xi[BW];
           SPICEY_UNROLL
-          for (int b = 0; b < 4; b++) xi[b] = P.out_x[i0 + b * T < P.nOut ? i0 + b * T : i0];
-          double v[4];
+          for (int b = 0; b < BW; b++) xi[b] = P.out_x[i0 + b * T < P.nOut ? i0 + b * T : i0];
+          double v[BW];
           SPICEY_UNROLL
-          for (int b = 0; b < 4; b++) v[b] = xi[b] < 0 ? 0.0 : c.W[(size_t)xi[b]];
+          for (int b = 0; b < BW; b++) v[b] = xi[b] < 0 ? 0.0 : c.W[(size_t)xi[b]];
           SPICEY_UNROLL
-          for (int b = 0; b < 4; b++)
+          for (int b = 0; b < BW; b++)
             if (i0 + b * T < P.nOut) SPICEY_STREAM_STORE(&ov[i0 + b * T], v[b]);
         }
         if (oi && (zrem & 2u))
         SPICEY_NOUNROLL
-        for (int i0 = tid + NEL * T; i0 < P.nR; i0 += 4 * T) {
-          uint32_t ab[4];
-          double gg[4], dv[4];
+        for (int i0 = tid + NEL * T; i0 < P.nR; i0 += BW * T) {
+          uint32_t ab[BW];
+          double gg[BW], dv[BW];
           SPICEY_UNROLL
-          for (int b = 0; b < 4; b++) { const int i = i0 + b * T < P.nR ? i0 + b * T : i0; ab[b] = P.R_ab[i]; gg[b] = g[i]; }
+          for (int b = 0; b < BW; b++) { const int i = i0 + b * T < P.nR ? i0 + b * T : i0; ab[b] = P.R_ab[i]; gg[b] = g[i]; }
           SPICEY_UNROLL
-          for (int b = 0; b < 4; b++) dv[b] = dv16(ab[b], k);
+          for (int b = 0; b < BW; b++) dv[b] = dv16(ab[b], k);
           SPICEY_UNROLL
-          for (int b = 0; b < 4; b++)
+          for (int b = 0; b < BW; b++)
             if (i0 + b * T < P.nR) SPICEY_STREAM_STORE(&oi[cR + i0 + b * T], dv[b] * gg[b]);
         }
         if (zrem & 4u)
         SPICEY_NOUNROLL
-        for (int i0 = tid + NEL * T; i0 < P.nC; i0 += 4 * T) {  // beyond the resident capacity: vPrev lives in the state array
-          uint32_t ab[4];
-          double gc[4], vp[4], dv[4];
+        for (int i0 = tid + NEL * T; i0 < P.nC; i0 += BW * T) {  // beyond the resident capacity: vPrev lives in the state array
+          uint32_t ab[BW];
+          double gc[BW], vp[BW], dv[BW];
           SPICEY_UNROLL
-          for (int b = 0; b < 4; b++) {
+          for (int b = 0; b < BW; b++) {
             const int i = i0 + b * T < P.nC ? i0 + b * T : i0;
             ab[b] = P.C_ab[i]; gc[b] = g[P.nR + i]; vp[b] = R.C_vprev[in * P.nC + i];
           }
           SPICEY_UNROLL
-          for (int b = 0; b < 4; b++) dv[b] = dv16(ab[b], k);
+          for (int b = 0; b < BW; b++) dv[b] = dv16(ab[b], k);
           SPICEY_UNROLL
-          for (int b = 0; b < 4; b++) {
+          for (int b = 0; b < BW; b++) {
             const int i = i0 + b * T;
             if (i >= P.nC) continue;
             z_cap(i, dv[b], k, in, gc[b], oi, cC, vp[b], false);
@@ -1533,19 +1538,19 @@ struct TranPhases2 {
         }
         if (zrem & 64u)
         SPICEY_NOUNROLL
-        for (int i0 = tid + NEL * T; i0 < P.nD; i0 += 4 * T) {
-          uint32_t ab[4];
-          double is4[4], d0[4], d1[4], vd[4];
+        for (int i0 = tid + NEL * T; i0 < P.nD; i0 += BW * T) {
+          uint32_t ab[BW];
+          double is4[BW], d0[BW], d1[BW], vd[BW];
           SPICEY_UNROLL
-          for (int b = 0; b < 4; b++) {
+          for (int b = 0; b < BW; b++) {
             const int i = i0 + b * T < P.nD ? i0 + b * T : i0;
             const double *dp = R.dpar + (in * P.nD + i) * 2;
             ab[b] = P.D_ab[i]; is4[b] = R.D_is[in * P.nD + i]; d0[b] = dp[0]; d1[b] = dp[1];
           }
           SPICEY_UNROLL
-          for (int b = 0; b < 4; b++) vd[b] = dv16(ab[b], k);
+          for (int b = 0; b < BW; b++) vd[b] = dv16(ab[b], k);
           SPICEY_UNROLL
-          for (int b = 0; b < 4; b++)
+          for (int b = 0; b < BW; b++)
             if (i0 + b * T < P.nD) z_dio(i0 + b * T, vd[b], k, in, is4[b], d0[b], d1[b], oi, cD, oD, last);
         }
       }

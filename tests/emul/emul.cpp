@@ -141,7 +141,11 @@ void run_groups(const HostProgram &hp, const SpiceyProg &P, SpiceyRun &R, int T,
       // rmax <= 8 takes the static-dispatch code path (RMAX = 8), larger the indexed-register path (RMAX = 16).
       if (P.hybrid) {
         if constexpr (K == 1) {
-          if (rmax <= 8) {
+          if (rmax == 6) {  // the 1024-thread build's shape: 6 slots, ONE element per thread, beyond-resident loops two at a time
+            std::vector<ResRegs<K, 6, 2, 1>> regs(T);
+            ex.rr = &regs;
+            spicey_tran_run_v2<K, 6, 2, 1, true>(ex, P, Q, R, c, g);
+          } else if (rmax <= 8) {
             std::vector<ResRegs<K, 8, 2, 2>> regs(T);
             ex.rr = &regs;
             spicey_tran_run_v2<K, 8, 2, 2, true>(ex, P, Q, R, c, g);

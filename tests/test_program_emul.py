@@ -144,9 +144,9 @@ def test_hybrid_workspace_layout_is_bit_identical(name, oracle_backend):
     flat, steps, dt, src = _inputs(name)
     ref = oracle_backend.run(flat, steps, dt, src)
     ran = 0
-    for rmax in (8, 16):
+    for rmax in (6, 8, 16):  # (6: the 1024-thread build's shape — 6 slots, one element per thread, loads two at a time)
         for kw in (dict(), dict(no_pcr=True), dict(no_rows=True)):
-            plain = EmulBackend(1, 64, False, rmax, **kw).run(flat, steps, dt, src)
+            plain = EmulBackend(1, 64, False, 8 if rmax == 6 else rmax, **kw).run(flat, steps, dt, src)
             be = EmulBackend(1, 64, False, rmax, hybrid=True, **kw)
             hy = be.run(flat, steps, dt, src)
             if hy["status"] == abi.ERR_BAD_DESC:  # no hybrid layout for this circuit (fewer than three levels)
@@ -169,8 +169,8 @@ def test_hybrid_workspace_layout_on_chains_and_reuse(oracle_backend):
         dt, steps = abi.computeEffectiveTimeStep(ckt.analyses["tran"]["dt"], ckt.analyses["tran"]["tstop"])
         flat, src = abi.flatten(ckt), abi.source_table(ckt, dt, steps)
         plain = EmulBackend(1, 128, False, 8).run(flat, steps, dt, src)
-        for kw in (dict(), dict(reverse=True), dict(no_reuse=True)):
-            be = EmulBackend(1, 128, kw.get("reverse", False), 8, no_reuse=kw.get("no_reuse", False), hybrid=True)
+        for kw in (dict(), dict(reverse=True), dict(no_reuse=True), dict(rmax=6)):
+            be = EmulBackend(1, 128, kw.get("reverse", False), kw.get("rmax", 8), no_reuse=kw.get("no_reuse", False), hybrid=True)
             hy = be.run(flat, steps, dt, src)
             assert hy["status"] == 0 and be.info["hybrid_entries"] > 0.3 * be.info["nnz_lu"]
             assert np.array_equal(hy["out_v"], plain["out_v"]) and np.array_equal(hy["out_i"], plain["out_i"])
