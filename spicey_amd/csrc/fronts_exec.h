@@ -87,7 +87,8 @@ struct FrontsRun {
     ex.mark(SPICEY_PH_U0 + 17);
   }
   // children's contribution blocks, in a fixed order; a child of another workgroup is waited for right before its turn
-  SPICEY_HD void assemble_children(const SpiceyFront &F, double *A, int lda, unsigned int epoch) const {
+  // `irel`: LDS scratch for the child's row / column map (q <= 192 words) — the parent's own LDS front ends before it
+  SPICEY_HD void assemble_children(const SpiceyFront &F, double *A, int lda, unsigned int epoch, uint32_t *irel) const {
     for (uint32_t ci = 0; ci < F.child_n; ci++) {  // extend-add
       const uint32_t cid = P.fr_child[F.child0 + ci];
       if (foreign(cid)) {
@@ -97,32 +98,91 @@ struct FrontsRun {
       const SpiceyFront C = P.fr[cid];
       const double *Ac = FW + C.off;
       const uint32_t *rel = P.fr_rel + C.rel0;
+      // the child's map goes to LDS first (one round trip for all of it): the block loop then has ONE dependent round trip
+      // per turn — the child's values and the parent's (both addresses known) — instead of map -> parent entry -> sum
       ex.wg_phase([&](int t) {
-        // a wave takes four rows of the contribution block at a time: their loads are issued together
+        for (int i = t; i < C.q; i += T) irel[i] = rel[i];
+      });
+      ex.wg_phase([&](int t) {
+        // a wave takes eight rows of the contribution block at a time: their loads are issued together
         const int nw = T >> 6, w = t >> 6, lane = t & 63;
-        for (int i0 = w * 4; i0 < C.q; i0 += nw * 4) {
+        for (int i0 = w * 8; i0 < C.q; i0 += nw * 8) {
           for (int j = lane; j <= C.q; j += 64) {
-            const int sc = j < C.q ? C.Pp + j : C.Mp, dc = j < C.q ? (int)rel[j] : F.Mp;
-            double v[4];
-            uint32_t rr[4];
+            const int sc = j < C.q ? C.Pp + j : C.Mp, dc = j < C.q ? (int)irel[j] : F.Mp;
+            double v[8], o[8];
+            double *dst[8];
             SPICEY_UNROLL
-            for (int b = 0; b < 4; b++) {
+            for (int b = 0; b < 8; b++) {
               const int i = i0 + b < C.q ? i0 + b : i0;
               v[b] = Ac[(size_t)(C.Pp + i) * C.ld + sc];
-              rr[b] = rel[i];
+              dst[b] = A + (size_t)irel[i] * lda + dc;
+              o[b] = *dst[b];
             }
-            double o[4];
             SPICEY_UNROLL
-            for (int b = 0; b < 4; b++) o[b] = A[(size_t)rr[b] * lda + dc];
-            SPICEY_UNROLL
-            for (int b = 0; b < 4; b++)
-              if (i0 + b < C.q) A[(size_t)rr[b] * lda + dc] = o[b] + v[b];
+            for (int b = 0; b < 8; b++)
+              if (i0 + b < C.q) *dst[b] = o[b] + v[b];
           }
         }
       });
     }
   }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the body of diag_block for the 64 lanes of ONE wave (also called from inside a trailing-update phase: look-ahead)
+  __device__ __forceinline__ void diag_block_wave(int t, double *Up, int su, double *Ld, double *Dinv) const {
+    const int i = t >> 2, jq = t & 3;
+    double a[4];
+#ifdef SPICEY_DIAG_TIMING
+    const long long c0 = clock64();
+#endif
+#pragma unroll
+    for (int m = 0; m < 4; m++) a[m] = Up[(size_t)i * su + jq + 4 * m];
+#ifdef SPICEY_DIAG_TIMING
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const long long c1 = clock64();
+#endif
+    double dkeep = 0.0;  // lane k < 16 keeps 1 / pivot k
+    double pmin = 1.0;   // smallest |pivot| so far (the identity padding behind the real rows has pivots of exactly 1)
+    double *Lrow = Ld + i * SPICEY_FB;
+#pragma unroll
+    for (int k = 0; k < SPICEY_FB; k++) {
+      // the pivot row first; the register that holds the NEXT pivot leads, so that its update is the first to finish
+      const int m0 = k + 1 < SPICEY_FB ? (k + 1) >> 2 : 3;
+      double u[4];
+#pragma unroll
+      for (int mm = 0; mm < 4; mm++) {
+        const int m = (m0 + mm) & 3;
+        u[m] = 4 * m + 3 > k ? __shfl(a[m], (k << 2) | jq) : 0.0;  // (columns <= k: nothing to update)
+      }
+      SPICEY_SCHED_FENCE;
+      const double piv = spicey_readlane_f64(a[k >> 2], (k << 2) | (k & 3));
+      const double d = spicey_rcp(piv);
+      pmin = fmin(pmin, fabs(piv));
+      dkeep = t == k ? d : dkeep;
+      const double l = spicey_quad_bcast_f64(a[k >> 2], k & 3) * d;
+      if (i > k) {  // (the store keeps this a branch: the updates inside run under its exec mask)
+        Lrow[k] = l;  // (the four lanes of the row's quad write the same value)
+#pragma unroll
+        for (int mm = 0; mm < 4; mm++) {
+          const int m = (m0 + mm) & 3;
+          if (4 * m > k) a[m] = fma(-l, u[m], a[m]);
+          else if (4 * m + 3 > k) a[m] = jq > (k & 3) ? fma(-l, u[m], a[m]) : a[m];  // the register that holds column k itself
+        }
+      }
+      SPICEY_SCHED_FENCE;
+    }
+#ifdef SPICEY_DIAG_TIMING
+    const long long c2 = clock64();
+#endif
+    if (t < SPICEY_FB) Dinv[t] = dkeep;
+    if (t == 0 && pmin < SPICEY_EPS && valid) { flags[1] = 1; flags[2] = inst; }  // solveReal.ts:28
+#pragma unroll
+    for (int m = 0; m < 4; m++) Up[(size_t)i * su + jq + 4 * m] = a[m];
+#ifdef SPICEY_DIAG_TIMING
+    if (t == 0 && ex.prof) { ex.prof[60] += (unsigned long long)(c1 - c0); ex.prof[61] += (unsigned long long)(c2 - c1); ex.prof[62] += (unsigned long long)(clock64() - c2); ex.prof[63] += 1; }
+#endif
+  }
+#endif
   // ---- 16 x 16 diagonal block of a panel: Up rows (stride su) in place, multipliers -> Ld, reciprocal pivots -> Dinv ----
   SPICEY_HD void diag_block(double *Up, int su, double *Ld, double *Dinv, int npiv_real) const {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -135,58 +195,7 @@ struct FrontsRun {
     // pivot is wave-uniform (v_readlane), the multiplier's source is in the lane's own quad (DPP quad_perm: a VALU move),
     // and only the pivot row goes through the LDS crossbar (ds_bpermute), issued ahead of the reciprocal.
     ex.wg_phase([&](int t) {
-      if (t >= 64) return;
-      const int i = t >> 2, jq = t & 3;
-      double a[4];
-#ifdef SPICEY_DIAG_TIMING
-      const long long c0 = clock64();
-#endif
-#pragma unroll
-      for (int m = 0; m < 4; m++) a[m] = Up[(size_t)i * su + jq + 4 * m];
-#ifdef SPICEY_DIAG_TIMING
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const long long c1 = clock64();
-#endif
-      double dkeep = 0.0;  // lane k < 16 keeps 1 / pivot k
-      double pmin = 1.0;   // smallest |pivot| so far (the identity padding behind the real rows has pivots of exactly 1)
-      double *Lrow = Ld + i * SPICEY_FB;
-#pragma unroll
-      for (int k = 0; k < SPICEY_FB; k++) {
-        // the pivot row first; the register that holds the NEXT pivot leads, so that its update is the first to finish
-        const int m0 = k + 1 < SPICEY_FB ? (k + 1) >> 2 : 3;
-        double u[4];
-#pragma unroll
-        for (int mm = 0; mm < 4; mm++) {
-          const int m = (m0 + mm) & 3;
-          u[m] = 4 * m + 3 > k ? __shfl(a[m], (k << 2) | jq) : 0.0;  // (columns <= k: nothing to update)
-        }
-        SPICEY_SCHED_FENCE;
-        const double piv = spicey_readlane_f64(a[k >> 2], (k << 2) | (k & 3));
-        const double d = spicey_rcp(piv);
-        pmin = fmin(pmin, fabs(piv));
-        dkeep = t == k ? d : dkeep;
-        const double l = spicey_quad_bcast_f64(a[k >> 2], k & 3) * d;
-        if (i > k) {  // (the store keeps this a branch: the updates inside run under its exec mask)
-          Lrow[k] = l;  // (the four lanes of the row's quad write the same value)
-#pragma unroll
-          for (int mm = 0; mm < 4; mm++) {
-            const int m = (m0 + mm) & 3;
-            if (4 * m > k) a[m] = fma(-l, u[m], a[m]);
-            else if (4 * m + 3 > k) a[m] = jq > (k & 3) ? fma(-l, u[m], a[m]) : a[m];  // the register that holds column k itself
-          }
-        }
-        SPICEY_SCHED_FENCE;
-      }
-#ifdef SPICEY_DIAG_TIMING
-      const long long c2 = clock64();
-#endif
-      if (t < SPICEY_FB) Dinv[t] = dkeep;
-      if (t == 0 && pmin < SPICEY_EPS && valid) { flags[1] = 1; flags[2] = inst; }  // solveReal.ts:28
-#pragma unroll
-      for (int m = 0; m < 4; m++) Up[(size_t)i * su + jq + 4 * m] = a[m];
-#ifdef SPICEY_DIAG_TIMING
-      if (t == 0 && ex.prof) { ex.prof[60] += (unsigned long long)(c1 - c0); ex.prof[61] += (unsigned long long)(c2 - c1); ex.prof[62] += (unsigned long long)(clock64() - c2); ex.prof[63] += 1; }
-#endif
+      if (t < 64) diag_block_wave(t, Up, su, Ld, Dinv);
     });
 #else
     // the same arithmetic with the block in memory: one wave in lockstep, step k eliminates column k
@@ -268,7 +277,9 @@ struct FrontsRun {
   // Device: 16 x 16 tiles, four v_mfma_f64_16x16x4 each (A = -L tile, B = U tile; operand maps: lane l holds A[l & 15][l >> 4]
   // and B[l >> 4][l & 15], result register r holds C[(l >> 4) + 4 r][l & 15]); the columns up to the next multiple of 16
   // exist behind C and the U panel (zero padding, left unchanged).  Host: the plain sum, k ascending.
-  template <int NT = 2>
+  // LOOK (look-ahead): wave 0 takes tile (0, 0) only — the next panel's diagonal block, which it then factors inside the
+  // same phase — and the other waves share the rest.
+  template <int NT = 2, bool LOOK = false>
   SPICEY_HD void trailing(double *C, int ldc, const double *Lp, int lpld, const double *Up, int su, int nrow, int ncol, int t) const {
     const int nw = T >> 6, w = t >> 6, lane = t & 63;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -283,7 +294,8 @@ struct FrontsRun {
     double *cl = C + (size_t)lk * ldc + li;          // + (16 ti + 4 r) ldc + 16 tj
     const double *al = Lp + (size_t)li * lpld + lk;  // + 16 ti lpld + 4 kk
     const double *bl = Up + (size_t)lk * su + li;    // + 4 kk su + 16 tj
-    const int dti = nw / tc, dtj = nw - dti * tc;    // the step from one tile of this wave to its next (row-major walk)
+    const int stride = LOOK ? (ws == 0 ? tr * tc : nw - 1) : nw;  // (LOOK: wave 0 stops after tile 0, waves 1.. walk tiles 1.. in steps of nw - 1)
+    const int dti = stride / tc, dtj = stride - dti * tc;  // the step from one tile of this wave to its next (row-major walk)
     int ti = ws / tc, tj = ws - ti * tc;
     while (ti < tr) {
       double *c0[NT];
@@ -476,10 +488,27 @@ struct FrontsRun {
       const int wU = F.Mp + 1 - j0, nL = F.Mp - j0 - SPICEY_FB;
       double *Up = A + (size_t)j0 * lda + j0, *Lp = A + (size_t)(j0 + SPICEY_FB) * lda + j0;
       ex.mark(SPICEY_PH_U0 + 13);
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (j0 == 0 || T < 128)  // (later panels: factored by wave 0 inside the previous panel's trailing update)
+#endif
       diag_block(Up, lda, Ld, Dinv, F.p - j0);
       ex.mark(SPICEY_PH_U0 + 14);
       ex.wg_phase([&](int t) { panel_trsm(Up, lda, Lp, lda, Ld, Dinv, nL, wU - SPICEY_FB, t); });
       ex.mark(SPICEY_PH_U0 + 15);
+#if defined(__HIP_DEVICE_COMPILE__)
+      // look-ahead: wave 0 updates the next panel's diagonal block first and factors it while the other waves finish the
+      // trailing update (the panel's two serial parts — that block and the triangular solves — no longer add up with it)
+      const bool more = j0 + SPICEY_FB < F.Pp;
+      if (more && T >= 128) {
+        ex.wg_phase([&](int t) {
+          if (t < SPICEY_FB) Up[(size_t)t * lda + t] = Dinv[t];
+          trailing<2, true>(Lp + SPICEY_FB, lda, Lp, lda, Up + SPICEY_FB, lda, nL, wU - SPICEY_FB, t);
+          if (t < 64) diag_block_wave(t, Lp + SPICEY_FB, lda, Ld, Dinv);  // (Lp + 16 = the (j0 + 16, j0 + 16) corner: the next Up)
+        });
+        ex.mark(SPICEY_PH_U0 + 16);
+        continue;
+      }
+#endif
       ex.wg_phase([&](int t) {
         if (t < SPICEY_FB) Up[(size_t)t * lda + t] = Dinv[t];  // reciprocal pivots on the diagonal: what the backward solve reads
         trailing(Lp + SPICEY_FB, lda, Lp, lda, Up + SPICEY_FB, lda, nL, wU - SPICEY_FB, t);
@@ -756,7 +785,7 @@ struct FrontsRun {
         double *A = ex.lds();
         const int lda = F.Mp + SPICEY_FRONT_LDS_PAD;
         assemble_own(F, A, lda);
-        assemble_children(F, A, lda, epoch);
+        assemble_children(F, A, lda, epoch, (uint32_t *)(A + (size_t)F.Mp * lda + 272));
         stamp(f, 0, t0);
         ex.mark(SPICEY_PH_U0 + 5);
         factor_lds(F, A, lda, A + (size_t)F.Mp * lda);
@@ -764,7 +793,7 @@ struct FrontsRun {
         store_lds_front(F, A, lda);
         ex.mark(SPICEY_PH_U0 + 7);
       } else {
-        assemble_children(F, FW + F.off, F.ld, epoch);
+        assemble_children(F, FW + F.off, F.ld, epoch, (uint32_t *)ex.lds());
         stamp(f, 0, t0);
         ex.mark(SPICEY_PH_U0 + 8);
         factor_global(F);
