@@ -698,7 +698,10 @@ struct FrontsRun {
   SPICEY_HD void solve(const SpiceyFront &F, bool wait_parent, unsigned int epoch, uint32_t f, unsigned long long t0) const {
     const double *A = FW + F.off;
     double *lds = ex.lds();
-    double *xs = lds, *tt = xs + F.Mp, *part = tt + F.Pp, *Ul = part + (size_t)F.Pp * 4;
+    // xs: the front's unknowns [Pp], behind them the boundary unknowns xb [Mp - Pp] once the parent's are there
+    double *xs = lds, *tt = xs + F.Mp, *part = tt + F.Pp;
+    uint32_t *ibnd = (uint32_t *)(part + (size_t)F.Pp * 4);  // the boundary's unknown ids [q]: fetched before the wait
+    double *Ul = part + (size_t)F.Pp * 4 + (F.Mp >> 1) + 1, *xb = xs + F.Pp;
     const uint32_t *bnd = P.fr_bnd + F.bnd0;
     const int lul = F.Mp + 1;  // (odd: a thread-per-row walk is bank-conflict free)
     const bool res = (size_t)(Ul - lds) + (size_t)F.p * (size_t)lul <= (size_t)R.front_lds_doubles;
@@ -707,6 +710,8 @@ struct FrontsRun {
     ex.wg_phase([&](int t) {
       SPICEY_NOUNROLL
       for (int i = t; i < F.Pp; i += T) tt[i] = i < F.p ? A[(size_t)i * F.ld + F.Mp] : 0.0;
+      SPICEY_NOUNROLL
+      for (int j = t; j < F.q; j += T) ibnd[j] = bnd[j];
       if (res) {
         const int nw = T >> 6, w = t >> 6, lane = t & 63;
         for (int i = w; i < F.p; i += nw) {
@@ -720,21 +725,27 @@ struct FrontsRun {
     stamp(f, 2, t0);
     ex.mark(SPICEY_PH_U0 + 10);
     if (F.q > 0) {
+      // the boundary unknowns into LDS first — ONE round trip to L2 for all of them (ids already here) — so that the product
+      // below runs from LDS alone (index -> unknown chains, four at a time per thread, were 2 x q / 16 dependent round
+      // trips: 8 us on the (71, 100) front)
+      ex.wg_phase([&](int t) {
+        const double *xW = W + (size_t)P.nLU;
+        SPICEY_NOUNROLL
+        for (int j = t; j < F.q; j += T) xb[j] = xW[ibnd[j]];
+      });
       ex.wg_phase([&](int t) {  // t = y_P - U_PB x_B: four partial sums per row, combined in a fixed order
         SPICEY_NOUNROLL
         for (int it = t; it < F.p * 4; it += T) {
           const int i = it >> 2, sg = it & 3;
           const double *row = U + (size_t)i * lu + F.Pp;
-          const double *xW = W + (size_t)P.nLU;
           double s = 0.0;
           int j = sg;
-          for (; j + 12 < F.q; j += 16) {  // four (index -> unknown) chains and four matrix loads in flight; the sum keeps its order
-            const uint32_t b0 = bnd[j], b1 = bnd[j + 4], b2 = bnd[j + 8], b3 = bnd[j + 12];
+          for (; j + 12 < F.q; j += 16) {  // four matrix loads in flight; the sum keeps its order
             const double r0 = row[j], r1 = row[j + 4], r2 = row[j + 8], r3 = row[j + 12];
-            const double x0 = xW[b0], x1 = xW[b1], x2 = xW[b2], x3 = xW[b3];
+            const double x0 = xb[j], x1 = xb[j + 4], x2 = xb[j + 8], x3 = xb[j + 12];
             s = fma(r0, x0, s); s = fma(r1, x1, s); s = fma(r2, x2, s); s = fma(r3, x3, s);
           }
-          for (; j < F.q; j += 4) s = fma(row[j], xW[bnd[j]], s);
+          for (; j < F.q; j += 4) s = fma(row[j], xb[j], s);
           part[it] = s;
         }
       });
