@@ -687,7 +687,12 @@ static int32_t build_program_impl(const SpiceyDesc *d, HostProgram &hp, std::str
     // group would be smaller than 8 workgroups (24 x 24: 32 instances 0.225 -> 0.186 with fronts, 64: 0.225 -> 0.209, 128:
     // 0.225 -> 0.304; 20 x 20 x 64: 0.152 -> 0.185): below ~16 k entries the fronts are for up to 32 instances only.
     const int64_t min_lu = d->n_inst <= 32 ? 6000 : 16000;
-    Lc = (nD + nS > 0 && nLU >= min_lu && nLevels > 24 && !hp.structurally_singular) ? 10 : 0;
+    // Level of the cut: 10, and 11 from ~7 000 unknowns on (round 3, after the front phases were rewritten for instruction
+    // count; R/C/diode meshes, one instance, ms per step at cut 9 / 10 / 11 / 12: 34 x 34 0.156 / 0.146 / 0.150 / 0.153,
+    // 70 x 70 0.241 / 0.232 / 0.238 / 0.241, 85 x 85 - / 0.323 / 0.321 / 0.332, 100 x 100 0.379 / 0.381 / 0.368 / 0.376,
+    // 120 x 120 - / 0.551 / 0.550 / 0.557): a lower cut turns the last sparse levels into many one-panel fronts (6 - 9 us
+    // each plus a hand-over on the chain that ends the sweep), a higher one adds workgroup-local levels below it.
+    Lc = (nD + nS > 0 && nLU >= min_lu && nLevels > 24 && !hp.structurally_singular) ? (n >= 7000 ? 11 : 10) : 0;
     if (const char *e = getenv("SPICEY_FRONT_CUT")) Lc = atoi(e);  // experiments
   }
   if (Lc >= nLevels || hp.structurally_singular) Lc = 0;
