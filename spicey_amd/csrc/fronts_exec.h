@@ -695,21 +695,32 @@ struct FrontsRun {
     });
 #endif
   }
+  // `in_lds`: the front is still in LDS from the forward sweep (stays_in_lds: q = 0) — its rows are read where they are, the
+  // scratch of this solve goes behind it (where the factorisation kept the multipliers of a diagonal block)
+  // (a template, not a run-time choice: a select between an LDS and a global pointer sends this hipcc into "Illegal
+  // instruction detected: Operand has incorrect register class")
+  template <bool in_lds = false>
   SPICEY_HD void solve(const SpiceyFront &F, bool wait_parent, unsigned int epoch, uint32_t f, unsigned long long t0) const {
-    const double *A = FW + F.off;
-    double *lds = ex.lds();
+    const int lda_l = F.Mp + SPICEY_FRONT_LDS_PAD;
+    const double *A;
+    double *lds;
+    if constexpr (in_lds) { A = ex.lds(); lds = ex.lds() + (size_t)F.Mp * lda_l; }
+    else { A = FW + F.off; lds = ex.lds(); }
+    const int ldA = in_lds ? lda_l : F.ld;
     // xs: the front's unknowns [Pp], behind them the boundary unknowns xb [Mp - Pp] once the parent's are there
     double *xs = lds, *tt = xs + F.Mp, *part = tt + F.Pp;
     uint32_t *ibnd = (uint32_t *)(part + (size_t)F.Pp * 4);  // the boundary's unknown ids [q]: fetched before the wait
     double *Ul = part + (size_t)F.Pp * 4 + (F.Mp >> 1) + 1, *xb = xs + F.Pp;
     const uint32_t *bnd = P.fr_bnd + F.bnd0;
     const int lul = F.Mp + 1;  // (odd: a thread-per-row walk is bank-conflict free)
-    const bool res = (size_t)(Ul - lds) + (size_t)F.p * (size_t)lul <= (size_t)R.front_lds_doubles;
-    const double *U = res ? Ul : A;  // where the block loop reads the U rows
-    const int lu = res ? lul : F.ld;
+    const bool res = !in_lds && (size_t)(Ul - lds) + (size_t)F.p * (size_t)lul <= (size_t)R.front_lds_doubles;
+    const double *U;  // where the block loop reads the U rows
+    if constexpr (in_lds) U = A;
+    else U = res ? Ul : A;
+    const int lu = res ? lul : ldA;
     ex.wg_phase([&](int t) {
       SPICEY_NOUNROLL
-      for (int i = t; i < F.Pp; i += T) tt[i] = i < F.p ? A[(size_t)i * F.ld + F.Mp] : 0.0;
+      for (int i = t; i < F.Pp; i += T) tt[i] = i < F.p ? A[(size_t)i * ldA + F.Mp] : 0.0;
       SPICEY_NOUNROLL
       for (int j = t; j < F.q; j += T) ibnd[j] = bnd[j];
       if (res) {
@@ -777,6 +788,12 @@ struct FrontsRun {
     });
   }
 
+  // A root front (no parent, no boundary) that lives in LDS and is the LAST front of its workgroup's list stays there between
+  // the sweeps: the backward sweep starts with it, from the same LDS block — no store of its U rows, no reload.
+  SPICEY_HD bool stays_in_lds(const SpiceyFront &F, uint32_t s, int w) const {
+    return Exec::keep_root && F.parent < 0 && F.q == 0 && s + 1 == R.fs_first[w + 1] && fits_lds(F);
+  }
+
   // ---- the two sweeps over this workgroup's share of the front tree -------------------------------------------
   SPICEY_HD unsigned long long forward(unsigned int epoch) const {
     const int w = ex.wg();
@@ -801,7 +818,7 @@ struct FrontsRun {
         ex.mark(SPICEY_PH_U0 + 5);
         factor_lds(F, A, lda, A + (size_t)F.Mp * lda);
         ex.mark(SPICEY_PH_U0 + 6);
-        store_lds_front(F, A, lda);
+        if (!stays_in_lds(F, s, w)) store_lds_front(F, A, lda);
         ex.mark(SPICEY_PH_U0 + 7);
       } else {
         assemble_children(F, FW + F.off, F.ld, epoch, (uint32_t *)ex.lds());
@@ -821,7 +838,12 @@ struct FrontsRun {
     for (uint32_t s = R.fs_first[w + 1]; s > R.fs_first[w]; s--) {
       const uint32_t f = R.fs_list[s - 1];
       const SpiceyFront F = P.fr[f];
-      solve(F, F.parent >= 0 && foreign((uint32_t)F.parent), epoch, f, t0);
+      bool kept = false;
+      if constexpr (Exec::keep_root) {
+        kept = stays_in_lds(F, s - 1, w);
+        if (kept) solve<true>(F, false, epoch, f, t0);
+      }
+      if (!kept) solve<false>(F, F.parent >= 0 && foreign((uint32_t)F.parent), epoch, f, t0);
       ex.mark(SPICEY_PH_U0 + 11);
       bool any = false;
       for (uint32_t ci = 0; ci < F.child_n; ci++) any = any || foreign(P.fr_child[F.child0 + ci]);

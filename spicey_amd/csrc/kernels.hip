@@ -55,6 +55,9 @@ __device__ __forceinline__ void gpu_wave_lockstep_keep(int nlanes, int nsteps, F
 }
 
 struct GpuExec {
+  // (fronts_exec.h: a root front stays in LDS between the sweeps — group kernel only: in the one-workgroup kernels with an LDS
+  // workspace the same code sends this hipcc into "Illegal instruction detected: Operand has incorrect register class")
+  static constexpr bool keep_root = false;
   // profiling clock (100 MHz, the same counter on every CU) and an accumulator bump by one thread
   __device__ __forceinline__ unsigned long long ticks_now() const { return (unsigned long long)wall_clock64(); }
   __device__ __forceinline__ void add_ticks(unsigned long long *dst, unsigned long long t0) const {
@@ -137,6 +140,7 @@ __global__ void __launch_bounds__(FRONTS ? 512 : 1024) spicey_tran_kernel(Spicey
 // Guideline 16).  All G workgroups are co-resident by construction (the host launches at most one per CU) and every
 // spin is bounded: on a timeout the abort word is set, every workgroup leaves, and the run reports an error.
 struct GpuGroupExec {
+  static constexpr bool keep_root = true;
   // profiling clock (100 MHz, the same counter on every CU) and an accumulator bump by one thread
   __device__ __forceinline__ unsigned long long ticks_now() const { return (unsigned long long)wall_clock64(); }
   __device__ __forceinline__ void add_ticks(unsigned long long *dst, unsigned long long t0) const {

@@ -17,6 +17,7 @@
 
 namespace {
 struct SeqExec {
+  static constexpr bool keep_root = true;  // (fronts_exec.h: a root front stays in LDS between the sweeps)
   int T;
   bool reverse;
   void *rr = nullptr;  // per-thread "registers" of the v2 interpreter: std::vector<Regs>*
