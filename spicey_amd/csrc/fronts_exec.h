@@ -408,7 +408,7 @@ struct FrontsRun {
 #endif
   }
   // the same update with a wave per tile COLUMN (for fronts with more panels than one fetch of the tile walk holds)
-  template <int CH = 5>
+  template <int CH = 5, int RT = 4>
   SPICEY_HD void trailing_left_cols(double *C, int ldc, int nrow, int ncol, int npan, const double *Lall, int Mp, int grow0, const double *A, int ld, int gcol0,
                                int t) const {
     const int nw = T >> 6, w = t >> 6, lane = t & 63;
@@ -416,10 +416,10 @@ struct FrontsRun {
     // Instruction economy as in trailing(): wave-uniform walk in scalar registers, lane parts of the addresses formed once.
     // The U rows come from the workspace (L2, ~1 us per round trip) and the MFMAs of a tile are nothing beside that, so the
     // walk is built around round trips: a wave owns a COLUMN of tiles — the U operands of that column (CH panels at a time;
-    // every staged front of the 100 x 100 mesh has at most 5) are fetched once and serve all its row tiles — and the C tile of
-    // the next row is fetched while the current one is multiplied.  With fewer tile columns than waves the rows of a column
+    // every staged front of the 100 x 100 mesh has at most 5) are fetched once and serve all its row tiles.  With fewer tile
+    // columns than waves the rows of a column
     // are dealt out to nw / tc waves.  (Tile by tile, one fetch per panel: 7 x 5 round trips per wave on the contribution
-    // block of the (71, 100) front; now 2 + 7 overlapped.)
+    // block of the (71, 100) front.)
     typedef double d4 __attribute__((ext_vector_type(4)));
     const int ws = SPICEY_UNIFORM(w);
     const int tr = nrow >> 4, tc = (ncol + 15) >> 4;
@@ -440,28 +440,38 @@ struct FrontsRun {
           const double *y = bl + (size_t)tj * 16 + (size_t)(p0 + c < npan ? p0 + c : p0) * SPICEY_FB * ld;  // (an absent panel repeats the chunk's first; not multiplied)
           bv[c][0] = y[0]; bv[c][1] = y[(size_t)4 * ld]; bv[c][2] = y[(size_t)8 * ld]; bv[c][3] = y[(size_t)12 * ld];
         }
-        double *cp = cl + ((size_t)row0 * 16 * ldc + (size_t)tj * 16);
-        d4 cn;
-        if (row0 < tr) { cn[0] = cp[0]; cn[1] = cp[(size_t)4 * ldc]; cn[2] = cp[(size_t)8 * ldc]; cn[3] = cp[(size_t)12 * ldc]; }
-        for (int ti = row0; ti < tr; ti += share) {
-          d4 acc = cn;
-          double *c0 = cp;
-          cp += (size_t)share * 16 * ldc;
-          if (ti + share < tr) { cn[0] = cp[0]; cn[1] = cp[(size_t)4 * ldc]; cn[2] = cp[(size_t)8 * ldc]; cn[3] = cp[(size_t)12 * ldc]; }
-          const double *la = al + (size_t)ti * 16 * SPICEY_LPLD;
-          int lo = lo0;
+        // the C tiles of this wave's rows of the column, RT at a time: ALL their loads go out together with the U operands
+        // above — one round trip to the workspace per RT tiles (with the next tile fetched under the current one it was one
+        // per tile; RT = 8 spills)
+        for (int tg = row0; tg < tr; tg += RT * share) {
+          d4 acc[RT];
           SPICEY_UNROLL
-          for (int c = 0; c < CH; c++) {
-            if (p0 + c < npan) {
-              const double *x = la + lo;
-              d4 av;
-              av[0] = x[0]; av[1] = x[4]; av[2] = x[8]; av[3] = x[12];
+          for (int r = 0; r < RT; r++) {
+            const int ti = tg + r * share < tr ? tg + r * share : tg;  // (wave-uniform; an absent tile repeats the group's first and is not stored)
+            const double *cp = cl + ((size_t)ti * 16 * ldc + (size_t)tj * 16);
+            acc[r][0] = cp[0]; acc[r][1] = cp[(size_t)4 * ldc]; acc[r][2] = cp[(size_t)8 * ldc]; acc[r][3] = cp[(size_t)12 * ldc];
+          }
+          SPICEY_UNROLL
+          for (int r = 0; r < RT; r++) {
+            const int ti = tg + r * share;
+            if (ti < tr) {
+              const double *la = al + (size_t)ti * 16 * SPICEY_LPLD;
+              int lo = lo0;
               SPICEY_UNROLL
-              for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[c][kk], acc, 0, 0, 0);
-              lo += SPICEY_LPLD * (Mp - 2 * SPICEY_FB - SPICEY_FB * (p0 + c));
+              for (int c = 0; c < CH; c++) {
+                if (p0 + c < npan) {
+                  const double *x = la + lo;
+                  d4 av;
+                  av[0] = x[0]; av[1] = x[4]; av[2] = x[8]; av[3] = x[12];
+                  SPICEY_UNROLL
+                  for (int kk = 0; kk < 4; kk++) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[c][kk], acc[r], 0, 0, 0);
+                  lo += SPICEY_LPLD * (Mp - 2 * SPICEY_FB - SPICEY_FB * (p0 + c));
+                }
+              }
+              double *c0 = cl + ((size_t)ti * 16 * ldc + (size_t)tj * 16);
+              c0[0] = acc[r][0]; c0[(size_t)4 * ldc] = acc[r][1]; c0[(size_t)8 * ldc] = acc[r][2]; c0[(size_t)12 * ldc] = acc[r][3];
             }
           }
-          c0[0] = acc[0]; c0[(size_t)4 * ldc] = acc[1]; c0[(size_t)8 * ldc] = acc[2]; c0[(size_t)12 * ldc] = acc[3];
         }
         for (int c = 0; c < CH && p0 + c < npan; c++) lo0 += SPICEY_LPLD * (Mp - 2 * SPICEY_FB - SPICEY_FB * (p0 + c));
       }
@@ -614,8 +624,7 @@ struct FrontsRun {
     // contribution block (rows and columns of the boundary, right-hand side included): every panel's products in one pass
     if (Mp > F.Pp)
       ex.wg_phase([&](int t) {
-        if (F.Pp > 4 * SPICEY_FB) trailing_left_cols(A + (size_t)F.Pp * ld + F.Pp, ld, Mp - F.Pp, Mp + 1 - F.Pp, F.Pp / SPICEY_FB, Lall, Mp, F.Pp, A, ld, F.Pp, t);
-        else trailing_left(A + (size_t)F.Pp * ld + F.Pp, ld, Mp - F.Pp, Mp + 1 - F.Pp, F.Pp / SPICEY_FB, Lall, Mp, F.Pp, A, ld, F.Pp, t);
+        trailing_left_cols(A + (size_t)F.Pp * ld + F.Pp, ld, Mp - F.Pp, Mp + 1 - F.Pp, F.Pp / SPICEY_FB, Lall, Mp, F.Pp, A, ld, F.Pp, t);
       });
     ex.mark(SPICEY_PH_U0 + 29);
   }
