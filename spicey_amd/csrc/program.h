@@ -219,6 +219,9 @@ struct SpiceyResident {
   // LDS), which removes tail_n - 1 workgroup barriers and phase dispatches from every solve.
   int32_t tail_first;
   int32_t tail_n;
+  // tridiagonal top: the first backward phase below it (<= 64 rows, each needs unknowns of the top only) is resident in the
+  // slots of WAVE 0 and runs there right behind the last stage of the top, inside the same barrier phase (0: none)
+  int32_t k_merge;
 };
 
 // Per-run, per-instance data (device pointers; instance-major arrays)

@@ -1616,9 +1616,21 @@ void spicey_build_resident(const HostProgram &hp, int T, int rmax, HostResident 
     std::vector<std::vector<Chunk>> per_wave(nWaves);
     std::vector<int> load(nWaves, 0);
     int next_chunk = 0;
+    // tridiagonal top: the first backward phase below it goes to wave 0 — the wave that solves the top runs it right behind
+    // the last stage (SpiceyResident::k_merge): one barrier phase less on the serial chain of every solve
+    if (hp.hdr.pcr_n > 0 && rmax > 0 && !getenv("SPICEY_NO_KMERGE")) {
+      const int pm = 2 * hp.hdr.nLevels - hp.hdr.pcr_level;
+      if (pm > 0 && pm < nPh - 1 && hp.ph_cnt[pm] > 0 && hp.ph_cnt[pm] <= 64 && rows_of(pm) == 0) {
+        per_wave[0].push_back({pm, 0, (int)hp.ph_cnt[pm], 0});
+        load[0]++;
+        out.k_merge = pm;
+        out.resident_tasks += hp.ph_cnt[pm];
+      }
+    }
     for (int p : order) {
       const int cnt = (int)hp.ph_cnt[p];
       if (cnt == 0) continue;
+      if (out.k_merge > 0 && p == out.k_merge) continue;  // (placed above)
       if (p >= out.tail_first && p < out.tail_first + out.tail_n) continue;  // lives in the LDS tail table
       const int nrow = rows_of(p), ngen = nrow > 0 ? (int)hp.fus_gen[p] : cnt;
       const int cg = (ngen + 63) / 64, cr = (nrow + 63) / 64;
@@ -1717,6 +1729,7 @@ SpiceyResident HostResident::bind(const void *base) const {
   r.T = T;
   r.tail_first = tail_first;
   r.tail_n = tail_n;
+  r.k_merge = k_merge;
   return r;
 }
 

@@ -74,7 +74,7 @@ void spicey_bank_cost(const HostProgram &hp, int64_t *cycles, int64_t *ideal);
 struct HostResident {
   std::vector<uint32_t> res, st_first, st_cnt, st_rhs, st_fus, st_desc;
   std::vector<int32_t> res_phase;
-  int rmax = 0, T = 0, tail_first = 0, tail_n = 0;
+  int rmax = 0, T = 0, tail_first = 0, tail_n = 0, k_merge = 0;
   int64_t resident_tasks = 0, streamed_tasks = 0;
   std::vector<uint8_t> blob;
   std::vector<size_t> offsets;

@@ -1773,6 +1773,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
   // are bit-identical to refactoring (SURVEY.md §8(d) "solve-only" rate; the reference itself never reuses).
   top_pack |= (P.nD == 0 && nS == 0 && P.nDynEnt == 0 && !R.no_reuse) ? 1 << 17 : 0;  // bit 17 = linear
   top_pack |= (Ph2::DIAG && R.skip_risk != nullptr) ? 1 << 18 : 0;  // bit 18 = diagnostics: look at the stamped matrix after B (spicey_skip_risk)
+  top_pack |= (K == 1 && pcr_n > 0 && Q.k_merge == k_begin && k_begin < 2 * nL - 1) ? 1 << 19 : 0;  // bit 19 = the first backward phase runs in the top's wave
   top_pack = SPICEY_UNIFORM(top_pack);
   for (int64_t step = 0; step <= steps && code == 0; step++) {
     int iter = 0;
@@ -1819,16 +1820,30 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
           spicey_uk_phase<K, RMAX, NSV, NEL, false>(Pf, Qf, c, ex.template regs<Regs>(tid), tid, T, p, p < 64 ? ((smask >> p) & 1) != 0 : true, linear && step > 0);
         });
       }
+      const int kmerge = (tp >> 19) & 1;
       if (pcr_n > 0) {
+        // (kmerge: wave 0 goes on with the first backward phase below the top — its records are resident in this wave's
+        // slots, its rows need unknowns of the top only, and the LDS operations of one wave execute in order)
+        auto merged_k = [&](int lane) {
+          const SpiceyProg Pf = ex.fresh(P);
+          const SpiceyResident Qf = ex.fresh(Q);
+          spicey_uk_phase<K, RMAX, NSV, NEL, true>(Pf, Qf, c, ex.template regs<Regs>(lane), lane, T, k_begin, false);
+        };
 #if defined(__HIP_DEVICE_COMPILE__)
         if (pcr_S >= 1 && pcr_S <= 6) {
           ex.wave_lockstep_keep(64, 1, [&](int lane, int, double *) {
             spicey_pcr_all<K>(c, (double *)c.tail, (const uint16_t *)(c.tail + 1024), pcr_n, pcr_S, lane);
+            if (kmerge) {
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              merged_k(lane);
+            }
           });
         } else
 #endif
-        ex.wave_lockstep_keep(64, pcr_S + 1, [&](int lane, int st, double *own) {
-          spicey_pcr_stage<K>(c, (double *)c.tail, (const uint16_t *)(c.tail + 1024), pcr_n, pcr_S, lane, st, own);
+        ex.wave_lockstep_keep(64, pcr_S + 1 + kmerge, [&](int lane, int st, double *own) {
+          if (st <= pcr_S) spicey_pcr_stage<K>(c, (double *)c.tail, (const uint16_t *)(c.tail + 1024), pcr_n, pcr_S, lane, st, own);
+          else merged_k(lane);
         });
       } else if (k_begin > u_end) {
         // the record of level l + 1 is fetched (LDS) while level l executes: one round trip less on the serial chain
@@ -1843,7 +1858,7 @@ SPICEY_HD void spicey_tran_run_v2(Exec &ex, const SpiceyProg &P, const SpiceyRes
                         else spicey_exec_rec16<K, true>(c, Pf.ovf16, r[0], r[1], r[2], r[3]);
                       });
       }
-      for (int p = k_begin; p < 2 * nL - 1; p++) {
+      for (int p = k_begin + kmerge; p < 2 * nL - 1; p++) {
         const int l = 2 * nL - 1 - p;
         ex.phase(SPICEY_PH_K0 + (l < 31 ? l : 31), [&](int tid) {
           const SpiceyProg Pf = ex.fresh(P);
