@@ -367,7 +367,13 @@ __global__ void __launch_bounds__(FRONTS ? 512 : 1024) spicey_tran_kernel_grp(Sp
   extern __shared__ __attribute__((aligned(16))) char smem[];  // scratch of the dense fronts
   WgCtx<K> c;
   const int G = R.wgs_per_group;
-  const int grp = (int)blockIdx.x / G, wgi = (int)blockIdx.x % G;
+  // Workgroups are dealt to the 8 XCDs round-robin by block index, and each XCD has its own L2.  The schedules (front tree by
+  // proportional mapping, bins of the subtree-local levels) give neighbouring parts of the elimination tree to neighbouring
+  // LOGICAL workgroups — so the logical index is laid out XCD-major: the G / 8 workgroups of one XCD are consecutive, a
+  // subtree of up to G / 8 workgroups hands its fronts on inside one L2.  (Nothing else depends on the mapping: the barrier
+  // takes its XCD membership from a census of HW_REG_XCC_ID.)
+  const int grp = (int)blockIdx.x / G, pb = (int)blockIdx.x % G;
+  const int wgi = (G & 7) == 0 ? (pb & 7) * (G >> 3) + (pb >> 3) : pb;
   const size_t nW = (size_t)P.nW * K, nU = (size_t)P.nU * K, nG = (size_t)P.nGdyn * K;
   const size_t stride = nW + nU + nG + (((size_t)P.nS * K + 1) >> 1);
   c.W = R.gW + (size_t)grp * stride;
@@ -389,7 +395,7 @@ __global__ void __launch_bounds__(FRONTS ? 512 : 1024) spicey_tran_kernel_grp(Sp
   ex.counter = gs; ex.abortf = gs + 1;
   ex.epoch = 0u; ex.bad = false;
   ex.lds_ = (double *)smem;
-  ex.prof = R.prof ? R.prof + (size_t)blockIdx.x * SPICEY_PH_SLOTS : nullptr;
+  ex.prof = R.prof ? R.prof + ((size_t)grp * G + wgi) * SPICEY_PH_SLOTS : nullptr;  // (by logical workgroup)
   ex.last = (unsigned long long)wall_clock64();
   ex.limit = R.grp_timeout_ticks;
   ex.s_ab = &s_abort;
