@@ -461,6 +461,30 @@ def test_throughput_geometry_two_workgroups_per_cu(oracle_backend):
     assert np.array_equal(lat["out_v"], got["out_v"]) and np.array_equal(lat["out_i"], got["out_i"])  # same bits in both geometries
 
 
+def test_first_backward_level_in_the_tops_wave_changes_no_bit(monkeypatch):
+    """SpiceyResident::k_merge (the first backward phase below a tridiagonal top runs in the top's wave) against the build
+    of the resident program where it stays a phase of its own (SPICEY_NO_KMERGE, read when the handle is created): the
+    same bits, single instance (1024 threads) and throughput geometry (two 512-thread workgroups per CU)."""
+    from spicey_amd.lib import Handle
+    flat, dt, steps, src = synth.chain_batch("diode_chain", 1000, [1, 2, 3, 4], tran=".tran 1e-6 4e-5")
+    outs = {}
+    for geometry in (1, 2):
+        for off in (False, True):
+            if off: monkeypatch.setenv("SPICEY_NO_KMERGE", "1")
+            else: monkeypatch.delenv("SPICEY_NO_KMERGE", raising=False)
+            h = Handle(flat, geometry=geometry)
+            try:
+                r = h.run(steps, dt, src)
+                assert r["status"] == 0, r["detail"]
+                outs[(geometry, off)] = r
+            finally:
+                h.close()
+        monkeypatch.delenv("SPICEY_NO_KMERGE", raising=False)
+        a, b = outs[(geometry, False)], outs[(geometry, True)]
+        assert np.array_equal(a["out_v"], b["out_v"]) and np.array_equal(a["out_i"], b["out_i"], equal_nan=True)
+    assert np.array_equal(outs[(1, False)]["out_v"], outs[(2, False)]["out_v"])
+
+
 def test_determinism_across_handles_and_geometries():
     """Regression: results must not depend on what ran before (stale scratch / registers) nor on the workgroup
     geometry.  The gather-form program has a fixed summation order, so outputs are bit-identical across thread

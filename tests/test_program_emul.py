@@ -360,6 +360,24 @@ def test_tridiagonal_top_is_found_on_chains_only(oracle_backend):
             assert np.array_equal(again["out_v"], outs[0]["out_v"]) and np.array_equal(again["out_i"], outs[0]["out_i"])
 
 
+def test_first_backward_level_runs_in_the_tridiagonal_tops_wave(monkeypatch):
+    """SpiceyResident::k_merge: with a tridiagonal top the first backward phase below it (<= 64 rows that need unknowns of
+    the top only) is resident in the slots of wave 0 and runs right behind the last stage of the cyclic reduction, inside
+    the same barrier phase.  Same records, same operands: bit-identical to the build where it is a phase of its own
+    (SPICEY_NO_KMERGE), in both thread orders and for both resident-slot code paths."""
+    for kind, n in (("diode_chain", 1000), ("rc_ladder", 300)):
+        flat, dt, steps, src = synth.chain_batch(kind, n, [1, 2], tran=".tran 1e-6 2e-5")
+        for T, rev, rmax in ((256, False, 8), (128, True, 16), (512, False, 4)):
+            monkeypatch.delenv("SPICEY_NO_KMERGE", raising=False)
+            merged = EmulBackend(1, T, rev, rmax).run(flat, steps, dt, src)
+            monkeypatch.setenv("SPICEY_NO_KMERGE", "1")
+            apart = EmulBackend(1, T, rev, rmax).run(flat, steps, dt, src)
+            monkeypatch.delenv("SPICEY_NO_KMERGE")
+            assert merged["status"] == 0 and apart["status"] == 0
+            for k in ("out_v", "out_i", "iters"):
+                assert np.array_equal(merged[k], apart[k], equal_nan=(k != "iters")), (kind, T, rmax, k)
+
+
 def test_tridiagonal_top_keeps_lu_accuracy_on_hard_driven_series_diodes(oracle_backend):
     """Parallel cyclic reduction is less forgiving than LU where rows are weakly diagonally dominant (series diodes driven
     hard).  Against an 80-bit replay of the reference algorithm the build with the tridiagonal top must stay far inside
