@@ -1545,6 +1545,12 @@ void HostProgram::pack() {
   add_section(blob, offsets, pos_row); add_section(blob, offsets, pos_col);      // 61 62
   add_section(blob, offsets, bin_upd); add_section(blob, offsets, bin_bk);       // 63 64
   add_section(blob, offsets, col_ptr); add_section(blob, offsets, col_ent);      // 65 66
+  if (getenv("SPICEY_DUMP_SECTIONS")) {  // experiments: bytes per section of the program blob
+    for (size_t i = 0; i < offsets.size(); i++) {
+      const size_t end = i + 1 < offsets.size() ? offsets[i + 1] : blob.size();
+      if (end - offsets[i] >= (1u << 16)) fprintf(stderr, "section %2zu: %9zu bytes\n", i, end - offsets[i]);
+    }
+  }
 }
 
 SpiceyProg HostProgram::bind(const void *base) const {
