@@ -191,7 +191,7 @@ static int32_t upload(SpiceyHandle *h, T **dst, const T *src, size_t count) {
   return SPICEY_OK;
 }
 
-extern "C" const char *spicey_version(void) { return "spicey_hip abi1 gfx950 (persistent LDS-resident sparse-LU transient kernel)"; }
+extern "C" const char *spicey_version(void) { return "spicey_hip abi2 gfx950 (persistent LDS-resident sparse-LU transient kernel)"; }
 
 extern "C" const char *spicey_last_error(SpiceyHandle *h) { return h ? h->err.c_str() : g_err.c_str(); }
 
