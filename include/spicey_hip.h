@@ -93,7 +93,8 @@ typedef struct SpiceyDesc {
 
 typedef struct SpiceyOptions {
   int32_t device;        /* HIP device ordinal */
-  int32_t threads;       /* workgroup size, 0 = auto */
+  int32_t threads;       /* workgroup size, 0 = auto (a circuit that takes the hybrid workspace, SpiceyInfo.hybrid_entries > 0, runs on
+                            1024 threads; 512 selects the 512-thread build of that kernel: the same results bit for bit) */
   int32_t inst_per_wg;   /* instances interleaved in one workgroup's LDS, 0 = auto */
   int32_t want_currents; /* 1: record element currents (out_i) */
   int32_t force_global;  /* 1: keep the LU workspace in HBM/L2 even if it fits LDS (testing) */
